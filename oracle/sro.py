@@ -1,0 +1,189 @@
+"""ctypes binding of the CPU oracle (oracle/libsro.so) — TEST INFRASTRUCTURE ONLY.
+
+Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (raytracing_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+HIT_DTYPE = np.dtype([("material", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("tri_index", "<i4")])
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libsro.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "libsro.so"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libsro.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.sro_last_error.restype = C.c_char_p
+        L.sro_scene_new.restype = C.c_void_p
+        for name in ("sro_scene_nodes", "sro_scene_packets", "sro_scene_tris", "sro_scene_arccos", "sro_scene_pdf"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.sro_scene_build_seconds.restype = C.c_double
+        L.sro_scene_build_seconds.argtypes = [C.c_void_p]
+        L.sro_primary_key.restype = C.c_uint64
+        L.sro_primary_key.argtypes = [C.c_uint64, C.c_uint64]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleScene:
+    """CPU restatement of PackagedScene + RayEngine for one scene description."""
+
+    def __init__(self, desc=None, build_tables=True, tables=None):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.sro_scene_new())
+        self._keep = []
+        if desc is not None:
+            self.load(desc, build_tables=build_tables, tables=tables)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.sro_scene_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("oracle: " + self.L.sro_last_error().decode())
+
+    def load(self, desc, build_tables=True, tables=None):
+        tris = np.ascontiguousarray(desc.tris)
+        self._chk(self.L.sro_scene_package(self.h, _p(tris), C.c_uint32(len(tris))))
+        mats = np.ascontiguousarray(desc.materials)
+        self._chk(self.L.sro_scene_set_materials(self.h, _p(mats), C.c_uint32(len(mats))))
+        for t in desc.textures:
+            img = np.ascontiguousarray(t.rgb8)
+            self.L.sro_scene_add_texture(self.h, _p(img), C.c_int32(img.shape[1]), C.c_int32(img.shape[0]),
+                                         C.c_float(t.scale[0]), C.c_float(t.scale[1]), C.c_int32(int(t.normal_transform)))
+        for d, e in desc.suns:
+            dd = np.asarray(d, np.float32); ee = np.asarray(e, np.float32)
+            self.L.sro_scene_add_sun(self.h, _p(dd), _p(ee))
+        self.L.sro_scene_set_params(self.h, C.c_int32(desc.max_generations), C.c_int32(desc.monte_carlo_max),
+                                    C.c_float(desc.monte_carlo_modifier))
+        if tables is not None:
+            a, p = tables
+            self.L.sro_scene_set_tables(self.h, _p(np.ascontiguousarray(a, np.float32)), _p(np.ascontiguousarray(p, np.float32)))
+        elif build_tables:
+            self.L.sro_scene_build_tables(self.h)
+
+    def set_params(self, max_generations, monte_carlo_max, monte_carlo_modifier):
+        self.L.sro_scene_set_params(self.h, C.c_int32(max_generations), C.c_int32(monte_carlo_max), C.c_float(monte_carlo_modifier))
+
+    # -- packaged arrays in the reference layouts (288 / 448 / 196 bytes per record)
+    def counts(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.L.sro_scene_counts(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def packaged(self):
+        nn, npk, nt = self.counts()
+        def grab(ptr, n, sz):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * sz,)).copy().reshape(n, sz)
+        return (grab(self.L.sro_scene_nodes(self.h), nn, 288), grab(self.L.sro_scene_packets(self.h), npk, 448),
+                grab(self.L.sro_scene_tris(self.h), nt, 196))
+
+    def tables(self):
+        a = np.ctypeslib.as_array(C.cast(self.L.sro_scene_arccos(self.h), C.POINTER(C.c_float)), shape=(2048,)).copy()
+        p = np.ctypeslib.as_array(C.cast(self.L.sro_scene_pdf(self.h), C.POINTER(C.c_float)), shape=(1024 * 1024,)).copy()
+        return a, p
+
+    def build_seconds(self):
+        return self.L.sro_scene_build_seconds(self.h)
+
+    # -- casts
+    def cast_closest(self, org, dirs, want_advanced=False):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(org)
+        out = np.zeros(n, HIT_DTYPE)
+        adv = np.zeros((n, 3), np.float32) if want_advanced else None
+        ctr = np.zeros(3, np.uint64)
+        self._chk(self.L.sro_cast_closest(self.h, _p(org), _p(dirs), C.c_uint32(n), _p(out), _p(adv), _p(ctr)))
+        return (out, ctr, adv) if want_advanced else (out, ctr)
+
+    def cast_shadow(self, org, dirs):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        lit = np.zeros(len(org), np.uint8)
+        self._chk(self.L.sro_cast_shadow(self.h, _p(org), _p(dirs), C.c_uint32(len(org)), _p(lit)))
+        return lit
+
+    def process_rays_keyed(self, org, dirs, keys, generation=0):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        keys = np.ascontiguousarray(keys, np.uint64)
+        rad = np.zeros((len(org), 3), np.float32)
+        st = np.zeros(8, np.uint64)
+        self._chk(self.L.sro_process_rays_keyed(self.h, _p(org), _p(dirs), _p(keys), C.c_int32(generation),
+                                                C.c_uint32(len(org)), _p(rad), _p(st)))
+        return rad, st
+
+    def render_pass(self, camera, rect, pass_index, seed, accum4, aux4=None, mode=0, threads=1):
+        cam = np.ascontiguousarray(camera)
+        x0, y0, w, h = rect
+        st = np.zeros(8, np.uint64)
+        self._chk(self.L.sro_render_pass(self.h, _p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w), C.c_int32(h),
+                                         C.c_uint32(pass_index), C.c_uint64(seed), C.c_int32(mode), C.c_int32(threads),
+                                         _p(accum4), _p(aux4), _p(st)))
+        return st
+
+
+def camera_rays_keyed(camera, rect, pass_index, seed):
+    cam = np.ascontiguousarray(camera)
+    x0, y0, w, h = rect
+    d = np.zeros((w * h, 3), np.float32)
+    k = np.zeros(w * h, np.uint64)
+    lib().sro_camera_rays_keyed(_p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w), C.c_int32(h), C.c_uint32(pass_index),
+                                C.c_uint64(seed), _p(d), _p(k))
+    return d, k
+
+
+def xorgen_stream(seed4, n_scalar, n_pools):
+    s = np.asarray(seed4, np.uint64)
+    sc = np.zeros(n_scalar, np.float32); po = np.zeros((n_pools, 8), np.float32); raw = np.zeros(4, np.uint64)
+    lib().sro_xorgen_stream(_p(s), C.c_uint32(n_scalar), C.c_uint32(n_pools), _p(sc), _p(po), _p(raw))
+    return sc, po, raw
+
+
+def keyed_stream(key, n_pools, n_scalar):
+    po = np.zeros((n_pools, 8), np.float32); sc = np.zeros(n_scalar, np.float32); ck = C.c_uint64()
+    lib().sro_keyed_stream(C.c_uint64(key), C.c_uint32(n_pools), C.c_uint32(n_scalar), _p(po), _p(sc), C.byref(ck))
+    return po, sc, ck.value
+
+
+def trig(x):
+    x = np.ascontiguousarray(x, np.float32)
+    s = np.zeros_like(x); c = np.zeros_like(x); t = np.zeros_like(x)
+    lib().sro_trig(_p(x), C.c_uint32(len(x)), _p(s), _p(c), _p(t))
+    return s, c, t
+
+
+def poly_acos(x):
+    x = np.ascontiguousarray(x, np.float32)
+    o = np.zeros_like(x)
+    lib().sro_poly_acos(_p(x), C.c_uint32(len(x)), _p(o))
+    return o

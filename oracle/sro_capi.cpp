@@ -1,0 +1,375 @@
+// oracle/sro_capi.cpp — TEST INFRASTRUCTURE ONLY (the parity oracle).
+//
+// extern "C" surface over the CPU restatement so tests/, smoke() and
+// bench.py's cpu_baseline leg can drive it through ctypes. The product never
+// links or loads this library. PARITY UNPINNED (see sro_math.h).
+#include "sro_shade.h"
+#include <chrono>
+#include <thread>
+#include <atomic>
+#include <string>
+
+using namespace sro;
+
+namespace {
+struct Handle {
+    Scene scene;
+    std::vector<std::vector<uint8_t>> tex_store;
+    std::string err;
+};
+thread_local std::string g_err;
+}  // namespace
+
+extern "C" {
+
+// Authoring triangle as handed over by the host (world space, already flattened).
+struct sro_tri_in {
+    float p[9];        // p1 p2 p3
+    float uv[6];       // UV_1 UV_2 UV_3
+    float n[9];        // vertex normals (used when flags&1, else the face normal — Primitives.h:238-252)
+    int32_t material;
+    uint32_t flags;
+};
+
+struct sro_material_in {           // mirrors sro::Material field order
+    float color[3];     int32_t color_tex;
+    float roughness;    int32_t roughness_tex;
+    float metallic;     int32_t metallic_tex;
+    float specular;     int32_t specular_tex;
+    float emissive[3];  int32_t emissive_tex;
+    float normal[3];    int32_t normal_tex;
+    float transmission; int32_t transmission_tex;
+    float ior;          int32_t ior_tex;
+    int32_t use_normals;
+};
+
+struct sro_hit { uint32_t material; float t, u, v; int32_t tri_index; };
+
+struct sro_camera_in {
+    float position[3]; float rotation[4]; float focal_position[3];
+    float lens_width, lens_height;
+    int32_t res_x, res_y, subdiv;
+};
+
+const char* sro_last_error() { return g_err.c_str(); }
+
+void* sro_scene_new() { return new Handle(); }
+void sro_scene_free(void* h) { delete (Handle*)h; }
+
+int sro_scene_package(void* hv, const sro_tri_in* tris, uint32_t n) {
+    Handle* h = (Handle*)hv;
+    try {
+        std::vector<Tri> v;
+        v.reserve(n);
+        for (uint32_t i = 0; i < n; i++) {
+            const sro_tri_in& t = tris[i];
+            Tri T(XYZ(t.p[0], t.p[1], t.p[2]), XYZ(t.p[3], t.p[4], t.p[5]), XYZ(t.p[6], t.p[7], t.p[8]),
+                  XY(t.uv[0], t.uv[1]), XY(t.uv[2], t.uv[3]), XY(t.uv[4], t.uv[5]), (short)t.material);
+            if (t.flags & 1u) {
+                T.n1 = XYZ(t.n[0], t.n[1], t.n[2]); T.n2 = XYZ(t.n[3], t.n[4], t.n[5]); T.n3 = XYZ(t.n[6], t.n[7], t.n[8]);
+            }
+            v.push_back(T);
+        }
+        h->scene.geo = PackagedGeometry();
+        auto t0 = std::chrono::steady_clock::now();
+        package(v, h->scene.geo);
+        h->scene.geo.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// Install already-packaged geometry (reference layouts) instead of building it.
+int sro_scene_set_packaged(void* hv, const void* nodes, uint32_t n_nodes, const void* packets, uint32_t n_packets,
+                           const void* tris, uint32_t n_tris) {
+    Handle* h = (Handle*)hv;
+    PackagedGeometry& g = h->scene.geo;
+    g.avx_bvh.assign((const BVH_AVX*)nodes, (const BVH_AVX*)nodes + n_nodes);
+    g.avx_tri_data.assign((const PTri_AVX*)packets, (const PTri_AVX*)packets + n_packets);
+    g.tri_data.assign((const PackagedTri*)tris, (const PackagedTri*)tris + n_tris);
+    return 0;
+}
+
+uint32_t sro_scene_counts(void* hv, uint32_t* n_nodes, uint32_t* n_packets, uint32_t* n_tris) {
+    Handle* h = (Handle*)hv;
+    *n_nodes = (uint32_t)h->scene.geo.avx_bvh.size();
+    *n_packets = (uint32_t)h->scene.geo.avx_tri_data.size();
+    *n_tris = (uint32_t)h->scene.geo.tri_data.size();
+    return 0;
+}
+const void* sro_scene_nodes(void* hv) { return ((Handle*)hv)->scene.geo.avx_bvh.data(); }
+const void* sro_scene_packets(void* hv) { return ((Handle*)hv)->scene.geo.avx_tri_data.data(); }
+const void* sro_scene_tris(void* hv) { return ((Handle*)hv)->scene.geo.tri_data.data(); }
+double sro_scene_build_seconds(void* hv) { return ((Handle*)hv)->scene.geo.build_seconds; }
+
+int sro_scene_set_materials(void* hv, const sro_material_in* m, uint32_t n) {
+    Handle* h = (Handle*)hv;
+    h->scene.materials.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        Material M;
+        M.color = XYZ(m[i].color[0], m[i].color[1], m[i].color[2]); M.color_tex = m[i].color_tex;
+        M.roughness = m[i].roughness; M.roughness_tex = m[i].roughness_tex;
+        M.metallic = m[i].metallic; M.metallic_tex = m[i].metallic_tex;
+        M.specular = m[i].specular; M.specular_tex = m[i].specular_tex;
+        M.emissive = XYZ(m[i].emissive[0], m[i].emissive[1], m[i].emissive[2]); M.emissive_tex = m[i].emissive_tex;
+        M.normal = XYZ(m[i].normal[0], m[i].normal[1], m[i].normal[2]); M.normal_tex = m[i].normal_tex;
+        M.transmission = m[i].transmission; M.transmission_tex = m[i].transmission_tex;
+        M.IOR = m[i].ior; M.IOR_tex = m[i].ior_tex;
+        M.use_normals = m[i].use_normals != 0;
+        h->scene.materials.push_back(M);
+    }
+    return 0;
+}
+
+int sro_scene_add_texture(void* hv, const uint8_t* rgb8, int32_t w, int32_t hgt, float sx, float sy, int32_t normal_transform) {
+    Handle* h = (Handle*)hv;
+    h->tex_store.emplace_back(rgb8, rgb8 + (size_t)w * hgt * 3);
+    Texture T;
+    T.resolution_x = w; T.resolution_y = hgt; T.scale = XY(sx, sy);
+    T.use_normal_transform = normal_transform != 0;
+    T.prep();
+    h->scene.textures.push_back(T);
+    for (size_t i = 0; i < h->scene.textures.size(); i++) h->scene.textures[i].data = h->tex_store[i].data();
+    return (int)h->scene.textures.size() - 1;
+}
+
+int sro_scene_add_sun(void* hv, const float* dir3, const float* emission3) {
+    Handle* h = (Handle*)hv;
+    SunLight L;
+    L.rotation = XYZ(dir3[0], dir3[1], dir3[2]);
+    L.emission = XYZ(emission3[0], emission3[1], emission3[2]);
+    h->scene.lights.push_back(L);
+    return 0;
+}
+
+int sro_scene_set_params(void* hv, int32_t max_generations, int32_t monte_carlo_max, float monte_carlo_modifier) {
+    Handle* h = (Handle*)hv;
+    h->scene.max_generations = (short)max_generations;
+    h->scene.monte_carlo_max = (short)monte_carlo_max;
+    h->scene.monte_carlo_modifier = monte_carlo_modifier;
+    return 0;
+}
+
+// Build (or install) the two lookup tables: arccos (2048) and the NDF inverse CDF (1024x1024).
+int sro_scene_build_tables(void* hv) {
+    Handle* h = (Handle*)hv;
+    build_arccos(h->scene.tables.arccos_lookup);
+    pdf::prep(h->scene.tables.pdf_lookup);
+    return 0;
+}
+int sro_scene_set_tables(void* hv, const float* arccos2048, const float* pdf1m) {
+    Handle* h = (Handle*)hv;
+    h->scene.tables.arccos_lookup.assign(arccos2048, arccos2048 + 2048);
+    h->scene.tables.pdf_lookup.assign(pdf1m, pdf1m + 1024 * 1024);
+    return 0;
+}
+const float* sro_scene_arccos(void* hv) { return ((Handle*)hv)->scene.tables.arccos_lookup.data(); }
+const float* sro_scene_pdf(void* hv) { return ((Handle*)hv)->scene.tables.pdf_lookup.data(); }
+
+// ---- casts ---------------------------------------------------------------
+// counters3 (optional) = {node visits, packet tests, max stack depth}.
+int sro_cast_closest(void* hv, const float* org3, const float* dir3, uint32_t n, sro_hit* out, float* advanced_org3,
+                     uint64_t* counters3) {
+    Handle* h = (Handle*)hv;
+    TraceCounters c;
+    try {
+        for (uint32_t i = 0; i < n; i++) {
+            XYZ o(org3[3 * i], org3[3 * i + 1], org3[3 * i + 2]);
+            XYZ d(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]);
+            CastResults r = execute_ray_cast(h->scene.geo, o, d, &c);
+            out[i].material = r.material;
+            out[i].t = r.TUV.X; out[i].u = r.TUV.Y; out[i].v = r.TUV.Z;
+            out[i].tri_index = r.tri_index;
+            if (advanced_org3) { advanced_org3[3 * i] = o.X; advanced_org3[3 * i + 1] = o.Y; advanced_org3[3 * i + 2] = o.Z; }
+        }
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+    if (counters3) { counters3[0] = c.nodes; counters3[1] = c.packets; counters3[2] = (uint64_t)c.max_stack; }
+    return 0;
+}
+
+// Shadow cast toward a sun direction: lit iff the closest hit is farther than 9999 (Primitives.h:44-50).
+int sro_cast_shadow(void* hv, const float* org3, const float* dir3, uint32_t n, uint8_t* lit) {
+    Handle* h = (Handle*)hv;
+    try {
+        for (uint32_t i = 0; i < n; i++) {
+            XYZ o(org3[3 * i], org3[3 * i + 1], org3[3 * i + 2]);
+            XYZ d(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]);
+            CastResults r = execute_ray_cast(h->scene.geo, o, d, nullptr);
+            lit[i] = r.distance > 9999 ? 1 : 0;
+        }
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+    return 0;
+}
+
+// ---- shading -------------------------------------------------------------
+// process_ray on a batch of rays with per-ray keyed RNG (the wavefront renderer's scheme).
+// stats8 (optional) = {rays_processed, diffuses_cast, shadows_cast, nodes, packets, shadow nodes, shadow packets, hits}
+int sro_process_rays_keyed(void* hv, const float* org3, const float* dir3, const uint64_t* keys, int32_t generation,
+                           uint32_t n, float* radiance3, uint64_t* stats8) {
+    Handle* h = (Handle*)hv;
+    RayEngine RE; RE.data = &h->scene; RE.keyed = true;
+    Diagnostics st;
+    try {
+        for (uint32_t i = 0; i < n; i++) {
+            PackagedRay r;
+            r.position = XYZ(org3[3 * i], org3[3 * i + 1], org3[3 * i + 2]);
+            r.slope = XYZ(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]);
+            r.generation = (signed char)generation;
+            r.key = keys[i];
+            XYZ L = RE.process_ray(st, r);
+            radiance3[3 * i] = L.X; radiance3[3 * i + 1] = L.Y; radiance3[3 * i + 2] = L.Z;
+        }
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+    if (stats8) {
+        stats8[0] = st.rays_processed; stats8[1] = st.diffuses_cast; stats8[2] = st.shadows_cast;
+        stats8[3] = st.trace.nodes; stats8[4] = st.trace.packets;
+        stats8[5] = st.shadow_trace.nodes; stats8[6] = st.shadow_trace.packets; stats8[7] = st.hits;
+    }
+    return 0;
+}
+
+static Camera make_camera(const sro_camera_in* c) {
+    Camera cam;
+    cam.position = XYZ(c->position[0], c->position[1], c->position[2]);
+    cam.rotation.X = c->rotation[0]; cam.rotation.Y = c->rotation[1]; cam.rotation.Z = c->rotation[2]; cam.rotation.W = c->rotation[3];
+    cam.focal_position = XYZ(c->focal_position[0], c->focal_position[1], c->focal_position[2]);
+    cam.width = c->lens_width; cam.height = c->lens_height;
+    cam.prep(c->res_x, c->res_y, c->subdiv);
+    return cam;
+}
+
+// Primary ray directions for a rectangle of pixels with the keyed RNG: writes dir3 and the post-jitter key.
+int sro_camera_rays_keyed(const sro_camera_in* c, int32_t x0, int32_t y0, int32_t w, int32_t hgt, uint32_t pass_index,
+                          uint64_t seed, float* dir3, uint64_t* keys) {
+    Camera cam = make_camera(c);
+    const uint64_t npix = (uint64_t)c->res_x * c->res_y;
+    size_t k = 0;
+    for (int y = y0; y < y0 + hgt; y++)
+        for (int x = x0; x < x0 + w; x++, k++) {
+            KeyedGen g;
+            g.s = KeyedGen::primary_key(seed, (uint64_t)pass_index * npix + (uint64_t)y * c->res_x + x);
+            XYZ d = cam.random_slope_at(x, y, (int)(pass_index % (uint32_t)(c->subdiv * c->subdiv)), g);
+            dir3[3 * k] = d.X; dir3[3 * k + 1] = d.Y; dir3[3 * k + 2] = d.Z;
+            keys[k] = g.s;
+        }
+    return 0;
+}
+
+// One sample pass over a pixel rectangle, accumulated with the running-mean contract
+// (SceneManager.h:204-236). accum4/aux4 are res_x*res_y float4 = (r,g,b,sample count).
+//   mode 0: keyed RNG (what the GPU renderer computes; non-finite samples are skipped)
+//   mode 1: reference RNG — one sequential XorGen per worker thread, non-finite samples redrawn
+// threads>1 splits rows over std::thread workers (interleaved rows, like assign_iterative_groups).
+// stats8 as in sro_process_rays_keyed. Returns 0 on success.
+int sro_render_pass(void* hv, const sro_camera_in* c, int32_t x0, int32_t y0, int32_t w, int32_t hgt,
+                    uint32_t pass_index, uint64_t seed, int32_t mode, int32_t threads, float* accum4, float* aux4,
+                    uint64_t* stats8) {
+    Handle* h = (Handle*)hv;
+    Camera cam = make_camera(c);
+    const uint64_t npix = (uint64_t)c->res_x * c->res_y;
+    const int spp = c->subdiv * c->subdiv;
+    if (threads < 1) threads = 1;
+    std::vector<Diagnostics> st(threads);
+    std::atomic<int> failed{0};
+    auto worker = [&](int tid) {
+        try {
+            RayEngine RE; RE.data = &h->scene; RE.keyed = (mode == 0);
+            XorGen xg;
+            xg.seed(seed + 1 + 4ull * tid + 1000003ull * pass_index, seed + 2 + 4ull * tid, seed + 3 + 4ull * tid, seed + 4 + 4ull * tid);
+            RE.shared_gen = &xg;
+            for (int y = y0 + tid; y < y0 + hgt; y += threads) {
+                for (int x = x0; x < x0 + w; x++) {
+                    XYZ res;
+                    for (;;) {
+                        PackagedRay ray;
+                        ray.position = cam.position;
+                        ray.generation = 0;
+                        if (mode == 0) {
+                            KeyedGen g;
+                            g.s = KeyedGen::primary_key(seed, (uint64_t)pass_index * npix + (uint64_t)y * c->res_x + x);
+                            ray.slope = cam.random_slope_at(x, y, (int)(pass_index % (uint32_t)spp), g);
+                            ray.key = g.s;
+                        } else {
+                            ray.slope = cam.random_slope_at(x, y, (int)(pass_index % (uint32_t)spp), xg);
+                        }
+                        res = RE.process_ray(st[tid], ray);
+                        if (res.wellDefined() || mode == 0) break;     // SceneManager.h:220-223 retry
+                    }
+                    if (!res.wellDefined()) continue;
+                    float* o = accum4 + 4 * ((size_t)y * c->res_x + x);
+                    {   // SceneManager.h:224-225
+                        int n = (int)o[3];
+                        XYZ cur(o[0], o[1], o[2]);
+                        cur *= (float)((double)n / (n + 1));
+                        cur += (float)(1.0 / (n + 1)) * res;
+                        o[0] = cur.X; o[1] = cur.Y; o[2] = cur.Z; o[3] = (float)(n + 1);
+                    }
+                    if (aux4 && (pass_index & 1u)) {   // add_aux toggles per pass starting false (:226-233)
+                        float* a = aux4 + 4 * ((size_t)y * c->res_x + x);
+                        int n = (int)a[3];
+                        XYZ cur(a[0], a[1], a[2]);
+                        cur *= (float)((double)n / (n + 1));
+                        cur += (float)(1.0 / (n + 1)) * res;
+                        a[0] = cur.X; a[1] = cur.Y; a[2] = cur.Z; a[3] = (float)(n + 1);
+                    }
+                }
+            }
+        } catch (const std::exception& e) { failed = 1; }
+    };
+    if (threads == 1) worker(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back(worker, t);
+        for (auto& t : pool) t.join();
+    }
+    if (failed) { g_err = "oracle render worker failed"; return 1; }
+    if (stats8) {
+        for (int i = 0; i < 8; i++) stats8[i] = 0;
+        for (auto& s : st) {
+            stats8[0] += s.rays_processed; stats8[1] += s.diffuses_cast; stats8[2] += s.shadows_cast;
+            stats8[3] += s.trace.nodes; stats8[4] += s.trace.packets;
+            stats8[5] += s.shadow_trace.nodes; stats8[6] += s.shadow_trace.packets; stats8[7] += s.hits;
+        }
+    }
+    return 0;
+}
+
+// ---- unit hooks for fixtures / parity of the small pieces -----------------
+void sro_xorgen_stream(const uint64_t* seed4, uint32_t n_scalar, uint32_t n_pools, float* scalars, float* pools8,
+                       uint64_t* raw) {
+    XorGen g; g.seed(seed4[0], seed4[1], seed4[2], seed4[3]);
+    for (uint32_t i = 0; i < n_pools; i++) { g.regen_pool(); for (int k = 0; k < 8; k++) pools8[8 * i + k] = g.pool[k]; }
+    for (uint32_t i = 0; i < n_scalar; i++) scalars[i] = g.fRand(0, 1);
+    if (raw) for (int i = 0; i < 4; i++) raw[i] = g.xe_next();
+}
+void sro_keyed_stream(uint64_t key, uint32_t n_pools, uint32_t n_scalar, float* pools8, float* scalars, uint64_t* child_key) {
+    KeyedGen g; g.s = key;
+    for (uint32_t i = 0; i < n_pools; i++) { g.regen_pool(); for (int k = 0; k < 8; k++) pools8[8 * i + k] = g.pool[k]; }
+    for (uint32_t i = 0; i < n_scalar; i++) scalars[i] = g.fRand(0, 1);
+    if (child_key) *child_key = g.child_key();
+}
+uint64_t sro_primary_key(uint64_t seed, uint64_t sample_index) { return KeyedGen::primary_key(seed, sample_index); }
+void sro_trig(const float* x, uint32_t n, float* s, float* c, float* t) {
+    for (uint32_t i = 0; i < n; i++) { s[i] = full_sin(x[i]); c[i] = full_cos(x[i]); t[i] = vtan(x[i]); }
+}
+void sro_poly_acos(const float* x, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; i++) out[i] = MaterialSample::poly_acos(x[i]);
+}
+void sro_vec_ops(const float* a3, const float* b3, uint32_t n, float* reflect3, float* cross3, float* norm3, float* dot1) {
+    for (uint32_t i = 0; i < n; i++) {
+        XYZ a(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]), b(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]);
+        XYZ r = XYZ::reflect(a, b), c = XYZ::cross(a, b), nn = XYZ::normalize(a);
+        reflect3[3 * i] = r.X; reflect3[3 * i + 1] = r.Y; reflect3[3 * i + 2] = r.Z;
+        cross3[3 * i] = c.X; cross3[3 * i + 1] = c.Y; cross3[3 * i + 2] = c.Z;
+        norm3[3 * i] = nn.X; norm3[3 * i + 1] = nn.Y; norm3[3 * i + 2] = nn.Z;
+        dot1[i] = XYZ::dot(a, b);
+    }
+}
+void sro_apply_rotation(const float* p3, const float* q4, uint32_t n, float* out3) {
+    for (uint32_t i = 0; i < n; i++) {
+        Quat q; q.X = q4[4 * i]; q.Y = q4[4 * i + 1]; q.Z = q4[4 * i + 2]; q.W = q4[4 * i + 3];
+        XYZ r = applyRotation(XYZ(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), q);
+        out3[3 * i] = r.X; out3[3 * i + 1] = r.Y; out3[3 * i + 2] = r.Z;
+    }
+}
+
+}  // extern "C"

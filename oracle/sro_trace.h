@@ -1,0 +1,155 @@
+// oracle/sro_trace.h — TEST INFRASTRUCTURE ONLY (the parity oracle).
+//
+// CPU restatement of the closest-hit cast: 8-wide slab test, nearest-first
+// child ordering, 8-triangle Moller-Trumbore, closest-hit select. Scalar loops
+// over the 8 AVX lanes with std::fmaf exactly where the reference has an FMA
+// intrinsic, x86 MINPS/MAXPS operand semantics for min/max.
+// PARITY UNPINNED (no upstream tests; see sro_math.h header and DESIGN.md).
+#pragma once
+#include "sro_scene.h"
+
+namespace sro {
+
+// Coredefs.h:6-15, Coredefs.cpp:6-9
+struct CastResults {
+    uint32_t material = 0xFFFFFFFFu;
+    float distance = 99999999999999999.f;
+    XYZ TUV = XYZ(-1);
+    XY texUV = XY(-1);
+    int tri_index = 0;
+};
+
+struct TraceCounters {
+    uint64_t nodes = 0;      // BVH_AVX::intersection calls (Core.h:70-72)
+    uint64_t packets = 0;    // PTri_AVX::intersection_check calls (Core.h:194-229)
+    int max_stack = 0;       // deepest stack_index + 1 reached
+};
+
+static inline float mm_min(float a, float b) { return a < b ? a : b; }   // vminps: NaN -> b
+static inline float mm_max(float a, float b) { return a > b ? a : b; }   // vmaxps: NaN -> b
+
+// BVH.h:940-988
+static inline void node_intersection(const BVH_AVX& n, const XYZ& fused, const XYZ& inv, float out[8]) {
+    for (int l = 0; l < 8; l++) {
+        float tx1 = std::fmaf(n.minX[l], inv.X, fused.X);
+        float tx2 = std::fmaf(n.maxX[l], inv.X, fused.X);
+        float ty1 = std::fmaf(n.minY[l], inv.Y, fused.Y);
+        float ty2 = std::fmaf(n.maxY[l], inv.Y, fused.Y);
+        float tz1 = std::fmaf(n.minZ[l], inv.Z, fused.Z);
+        float tz2 = std::fmaf(n.maxZ[l], inv.Z, fused.Z);
+        float tminx = mm_min(tx1, tx2), tminy = mm_min(ty1, ty2), tminz = mm_min(tz1, tz2);
+        float tmaxx = mm_max(tx1, tx2), tmaxy = mm_max(ty1, ty2), tmaxz = mm_max(tz1, tz2);
+        float tmin = mm_max(tminz, mm_max(tminy, tminx));
+        float tmax = mm_min(tmaxz, mm_min(tmaxy, tmaxx));
+        bool hit = (tmax >= 0.0f) && (tmin < tmax);   // _CMP_GE_OQ, _CMP_LT_OQ
+        out[l] = hit ? tmin : 0.0f;                    // and_ps with the mask
+    }
+}
+
+// Primitives.h:159-202 with VecLib.cpp:282-325
+static inline void packet_intersection(const PTri_AVX& T, const XYZ& o, const XYZ& d, float t[8], float u[8], float v[8]) {
+    for (int l = 0; l < 8; l++) {
+        const float e1x = T.p1p2X[l], e1y = T.p1p2Y[l], e1z = T.p1p2Z[l];
+        const float e2x = T.p1p3X[l], e2y = T.p1p3Y[l], e2z = T.p1p3Z[l];
+        // pvec = cross_avx(slope, p1p3)
+        float c1 = d.Z * e2y, c2 = d.X * e2z, c3 = d.Y * e2x;
+        float px = std::fmaf(d.Y, e2z, -c1), py = std::fmaf(d.Z, e2x, -c2), pz = std::fmaf(d.X, e2y, -c3);
+        // det = dot_avx(p1p2, pvec)
+        float det = std::fmaf(e1z, pz, std::fmaf(e1y, py, e1x * px));
+        float invDet = 1.0f / det;
+        float tx = o.X - T.p1X[l], ty = o.Y - T.p1Y[l], tz = o.Z - T.p1Z[l];
+        // qvec = cross_avx(tvec, p1p2)
+        float q1 = tz * e1y, q2 = tx * e1z, q3 = ty * e1x;
+        float qx = std::fmaf(ty, e1z, -q1), qy = std::fmaf(tz, e1x, -q2), qz = std::fmaf(tx, e1y, -q3);
+        float uu = invDet * std::fmaf(tz, pz, std::fmaf(ty, py, tx * px));
+        float vv = invDet * std::fmaf(d.Z, qz, std::fmaf(d.Y, qy, d.X * qx));
+        float tt = invDet * std::fmaf(e2z, qz, std::fmaf(e2y, qy, e2x * qx));
+        bool pass = (uu >= 0.0f) && (vv >= 0.0f) && ((uu + vv) <= 1.0f);
+        t[l] = pass ? tt : 0.0f;
+        u[l] = uu;
+        v[l] = vv;
+    }
+}
+
+// Core.h:49-244
+static inline void iterativeBVH_AVX(const PackagedGeometry& data, CastResults& res, const XYZ& position,
+                                    const XYZ& slope, TraceCounters* ctr) {
+    XYZ fused = (-1 * position) / slope;          // Core.h:53
+    XYZ inv = float_div_xyz(1, slope);            // Core.h:54
+    const int STACK = 256;                        // Scene.h:181
+    int stack[STACK];
+    float distances[STACK];
+    int tri_count[STACK];
+    int stack_index = 0;
+    stack[0] = 0; distances[0] = 0; tri_count[0] = 0;
+    int maxdepth = 1;
+    while (stack_index >= 0) {
+        const float dist = distances[stack_index];
+        const int self_triangles = tri_count[stack_index];
+        if (dist >= res.distance) { stack_index--; continue; }
+        if (self_triangles == 0) {
+            const BVH_AVX& current = data.avx_bvh[stack[stack_index]];
+            stack_index--;
+            float persist[8];
+            node_intersection(current, fused, inv, persist);
+            if (ctr) ctr->nodes++;
+            float results[8];
+            for (int l = 0; l < 8; l++) {               // Core.h:74-78
+                bool allow = (persist[l] != 0.0f);      // _CMP_NEQ_OQ (never NaN here)
+                uint32_t b = (bitcast<uint32_t>(persist[l]) & ~7u) | (uint32_t)l;
+                results[l] = allow ? bitcast<float>(b) : 0.0f;
+            }
+            int sorted_size = 0;
+            for (int i = 0; i < 8; i++) {               // Core.h:84-97
+                float num = results[i];
+                if (num != 0) {
+                    int j = sorted_size - 1;
+                    for (; j >= 0; j--) {
+                        if (results[j] > num) results[j + 1] = results[j];
+                        else break;
+                    }
+                    results[j + 1] = num;
+                    sorted_size++;
+                }
+            }
+            for (int i = sorted_size - 1; i >= 0; i--) { // Core.h:98-106
+                unsigned sel = bitcast<uint32_t>(results[i]) & 7u;
+                stack_index++;
+                if (stack_index >= STACK) throw std::runtime_error("oracle traversal stack overflow (reference UB)");
+                stack[stack_index] = (int)current.indexes[sel];
+                distances[stack_index] = persist[sel];
+                tri_count[stack_index] = (int)current.leaf_size[sel];
+            }
+            if (stack_index + 1 > maxdepth) maxdepth = stack_index + 1;
+        } else {
+            int start_index = stack[stack_index];
+            stack_index--;
+            for (int i = 0; i < self_triangles; i++) {
+                const PTri_AVX& P = data.avx_tri_data[i + start_index];
+                float t[8], u[8], v[8];
+                packet_intersection(P, position, slope, t, u, v);
+                if (ctr) ctr->packets++;
+                for (int l = 0; l < 8; l++) {           // Core.h:231-239
+                    if (t[l] > 0 && t[l] < res.distance) {
+                        res.distance = t[l];
+                        res.material = P.materials[l];
+                        res.TUV = XYZ(t[l], u[l], v[l]);
+                        res.tri_index = P.index + l;
+                    }
+                }
+            }
+        }
+    }
+    if (ctr && maxdepth > ctr->max_stack) ctr->max_stack = maxdepth;
+}
+
+// Core.h:323-329,346-350 — origin is advanced in place, even on a miss.
+static inline CastResults execute_ray_cast(const PackagedGeometry& data, XYZ& position, const XYZ& slope,
+                                           TraceCounters* ctr = nullptr) {
+    CastResults r;
+    iterativeBVH_AVX(data, r, position, slope, ctr);
+    position += r.distance * slope * 0.999f;
+    return r;
+}
+
+}  // namespace sro
