@@ -1,0 +1,184 @@
+/* include/srx.h — C-ABI of the MI355X trace-and-shade path ("srx").
+ *
+ * The reference (CharlesCowdery/RayTracing, directory spatialPartitioning/) has
+ * no FFI: its seam is the header-only C++ class `RayEngine` (Core.h:36-48). This
+ * C-ABI sits underneath that seam; every entry point below names the reference
+ * interface it replaces. Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure, and
+ * `srx_last_error()` then describes the failure (the reference throws C++
+ * exceptions instead: Primitives.h:34, BVH.h:1040). Nothing is thrown across
+ * this boundary. "device pointer" = HIP device memory on the current device.
+ * A scene handle is immutable after creation and may be shared by threads; a
+ * renderer handle owns scratch queues and must be used by one thread at a time.
+ */
+#ifndef SRX_H
+#define SRX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srx_package srx_package;
+typedef struct srx_scene srx_scene;
+typedef struct srx_renderer srx_renderer;
+
+/* Authoring triangle in world space = one `Tri` (Primitives.h:224-258) after
+ * `Object::fetchData` flattening (Primitives.h:423-434). flags bit0: vertex
+ * normals `n` are given (else the face normal is used, as the Tri ctor does). */
+typedef struct srx_tri {
+    float p[9];
+    float uv[6];
+    float n[9];
+    int32_t material;
+    uint32_t flags;
+} srx_tri;
+
+/* One `Material` (Materials.h:317-358) as plain data: each parameter is a
+ * constant or, when its *_tex id is >= 0, a texture (Texture.h:306-313). */
+typedef struct srx_material {
+    float color[3];     int32_t color_tex;
+    float roughness;    int32_t roughness_tex;
+    float metallic;     int32_t metallic_tex;
+    float specular;     int32_t specular_tex;
+    float emissive[3];  int32_t emissive_tex;
+    float normal[3];    int32_t normal_tex;
+    float transmission; int32_t transmission_tex;
+    float ior;          int32_t ior_tex;
+    int32_t use_normals;
+} srx_material;
+
+/* One `Texture<T>` (Texture.h:33-280, USE_CHAR 1): row-major RGB8 texels; a
+ * float-valued texture keeps its value in byte 0 of each texel. */
+typedef struct srx_texture {
+    const uint8_t* rgb8;
+    int32_t width, height;
+    float scale_x, scale_y;       /* KHR_texture_transform scale (Texture.h:73,227-230) */
+    int32_t normal_transform;     /* (c-128)/127 decode (Texture.h:151-153) */
+} srx_texture;
+
+/* `SunLight` (Primitives.h:39-51): `direction` is what vectorTo() returns (not normalised). */
+typedef struct srx_sun {
+    float direction[3];
+    float emission[3];
+} srx_sun;
+
+/* `PackagedScene` (Scene.h:18-31) as pointers + counts, records in the reference
+ * layouts: BVH_AVX 288 B (BVH.h:874-881), PTri_AVX 448 B (Primitives.h:127-134),
+ * PackagedTri 196 B (Primitives.h:62-81). Everything is deep-copied at create. */
+typedef struct srx_scene_desc {
+    const void* nodes;     uint32_t n_nodes;
+    const void* packets;   uint32_t n_packets;
+    const void* tris;      uint32_t n_tris;
+    const srx_material* materials; uint32_t n_materials;
+    const srx_texture* textures;   uint32_t n_textures;
+    const srx_sun* suns;           uint32_t n_suns;
+    int32_t max_generations;       /* Scene.h:28 */
+    int32_t monte_carlo_max;       /* Scene.h:29 */
+    float monte_carlo_modifier;    /* Scene.h:30 */
+    const float* pdf_lookup;       /* 1024*1024 floats (PDF.h:83-123) or NULL: built by the library */
+    const float* arccos_lookup;    /* 2048 floats (VecLib.cpp:391-398) or NULL: built by the library */
+} srx_scene_desc;
+
+/* Bit-compatible subset of `CastResults` (Coredefs.h:6-15): miss = material 0xFFFFFFFF, t=u=v=-1, tri_index 0. */
+typedef struct srx_hit {
+    uint32_t material;
+    float t, u, v;
+    int32_t tri_index;
+} srx_hit;
+
+/* `Camera` + `RectLens` (Camera.h:32-140). */
+typedef struct srx_camera {
+    float position[3];
+    float rotation[4];            /* quaternion x y z w */
+    float focal_position[3];
+    float lens_width, lens_height;
+    int32_t res_x, res_y, subdiv; /* subdiv^2 strata per pixel */
+} srx_camera;
+
+/* Counters of one call; `rays_processed`/`diffuses_cast` are `Casting_Diagnostics` (Coredefs.h:17-23). */
+typedef struct srx_counters {
+    uint64_t rays_processed;      /* process_ray invocations (Core.h:360) */
+    uint64_t diffuses_cast;       /* child rays queued (Core.h:595) */
+    uint64_t shadows_cast;        /* execute_lighting_cast calls (Core.h:351) */
+    uint64_t nodes;               /* 8-wide node tests by closest-hit casts (Core.h:70-72) */
+    uint64_t packets;             /* 8-triangle packet tests by closest-hit casts (Core.h:194-229) */
+    uint64_t shadow_nodes;
+    uint64_t shadow_packets;
+    uint64_t hits;                /* shaded hits */
+    uint64_t texels;              /* texture fetches */
+    uint64_t pdf_lookups;         /* NDF table fetches */
+    uint64_t trace_launches;      /* closest-hit kernel launches in this call */
+    double trace_ms;              /* summed closest-hit kernel time, HIP events on the launch stream (0 unless timing is on) */
+    uint64_t shadow_launches;
+    double shadow_ms;
+    uint64_t shade_launches;
+    double shade_ms;
+} srx_counters;
+
+const char* srx_last_error(void);
+
+/* Select the HIP device for this thread and check that it is gfx950-class. */
+int srx_init(int device);
+
+/* ---- host packager: replaces `Scene::package()` (Scene.h:90-179) = BVH::construct (BVH.h:98-180)
+ * + BVH_AVX::collapse (BVH.h:989-1077) + the PTri_AVX regroup (Scene.h:142-173). */
+int srx_package_create(const srx_tri* tris, uint32_t n_tris, srx_package** out);
+int srx_package_get(const srx_package* pkg, const void** nodes, uint32_t* n_nodes, const void** packets,
+                    uint32_t* n_packets, const void** tris, uint32_t* n_tris);
+void srx_package_destroy(srx_package* pkg);
+
+/* Lookup tables: `VecLib::prep` arccos table (VecLib.cpp:391-398) and `PDF::prep` (PDF.h:83-123). */
+int srx_build_tables(float* arccos2048, float* pdf1m);
+
+/* ---- scene upload: replaces `RayEngine::load_scene(PackagedScene*)` (Core.h:46-48). */
+int srx_scene_create(const srx_scene_desc* desc, srx_scene** out);
+void srx_scene_destroy(srx_scene* scene);
+/* worst-case traversal stack depth of this scene's tree (the reference reserves 256, Scene.h:181) */
+int srx_scene_stack_bound(const srx_scene* scene);
+
+/* ---- casts: replace `RayEngine::execute_ray_cast(XYZ&, const XYZ&)` (Core.h:346) over a batch.
+ * Host-pointer form copies in and out; the _device form takes device pointers and a hipStream_t
+ * (as void*) and is asynchronous. org3/dir3 are n*3 floats; `advanced_org3` (optional) receives the
+ * origin after the reference's in-place advance `o += t*d*0.999f` (Core.h:327).
+ * counters2 (optional, host) receives {node tests, packet tests}. */
+int srx_cast_closest(srx_scene* scene, const float* org3, const float* dir3, uint32_t n, srx_hit* hits,
+                     float* advanced_org3, uint64_t* counters2);
+int srx_cast_closest_device(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, srx_hit* d_hits,
+                            uint64_t* d_counters2, void* stream);
+/* replace `RayEngine::execute_lighting_cast(XYZ, Light*)` (Core.h:351-358) for sun lights:
+ * lit[i] = 1 iff the closest hit along dir is farther than 9999 (Primitives.h:44-50). */
+int srx_cast_shadow(srx_scene* scene, const float* org3, const float* dir3, uint32_t n, uint8_t* lit);
+int srx_cast_shadow_device(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, uint8_t* d_lit,
+                           void* stream);
+
+/* ---- wavefront renderer: replaces the `RenderThread::process_iteratively` loop around
+ * `RayEngine::process_ray` (SceneManager.h:193-237, Core.h:359-601).
+ * `ray_capacity` = number of ray slots in the device queues (48 B ray + 20 B hit + shadow records each). */
+int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_renderer** out);
+void srx_renderer_destroy(srx_renderer* r);
+/* 1 = bracket kernels with HIP events on the launch stream and report ms in srx_counters */
+int srx_renderer_set_timing(srx_renderer* r, int enabled);
+
+/* One sample pass over the pixel rectangle [x0,x0+w) x [y0,y0+h): primary rays from `camera`
+ * (stratum pass_index % subdiv^2, jitter from the per-sample keyed stream), full branched shading,
+ * then the running-mean accumulation of SceneManager.h:224-229 into d_accum4 and (odd passes) d_aux4:
+ * device arrays of res_x*res_y float4 = (r, g, b, sample count). Non-finite samples are skipped.
+ * Synchronous: returns when the pass is complete. `counters` optional (host). */
+int srx_trace_pass(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                   uint32_t pass_index, uint64_t seed, float* d_accum4, float* d_aux4, srx_counters* counters);
+
+/* `process_ray` on an explicit batch of rays (host arrays): ray i starts at generation `generation`
+ * with keyed RNG state keys[i]; radiance3[i] receives the returned XYZ. Used by parity tests. */
+int srx_process_rays(srx_renderer* r, const float* org3, const float* dir3, const uint64_t* keys, int32_t generation,
+                     uint32_t n, float* radiance3, srx_counters* counters);
+
+/* Primary ray directions + post-jitter RNG keys for a pixel rectangle (host outputs):
+ * `Camera::random_slope_at` (Camera.h:138-140) on the device. */
+int srx_camera_rays(const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h, uint32_t pass_index,
+                    uint64_t seed, float* dir3, uint64_t* keys);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRX_H */

@@ -1,0 +1,74 @@
+"""ctypes loader for raytracing_amd/libsrx.so (the C-ABI of include/srx.h).
+
+There is no fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsrx.so")
+
+# every symbol include/srx.h declares; tests check the library exports all of them
+EXPORTS = [
+    "srx_last_error", "srx_init",
+    "srx_package_create", "srx_package_get", "srx_package_destroy", "srx_build_tables",
+    "srx_scene_create", "srx_scene_destroy", "srx_scene_stack_bound",
+    "srx_cast_closest", "srx_cast_closest_device", "srx_cast_shadow", "srx_cast_shadow_device",
+    "srx_renderer_create", "srx_renderer_destroy", "srx_renderer_set_timing",
+    "srx_trace_pass", "srx_process_rays", "srx_camera_rays",
+]
+
+
+class SrxError(RuntimeError):
+    pass
+
+
+class SrxTexture(C.Structure):
+    _fields_ = [("rgb8", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("scale_x", C.c_float),
+                ("scale_y", C.c_float), ("normal_transform", C.c_int32)]
+
+
+class SrxSceneDesc(C.Structure):
+    _fields_ = [
+        ("nodes", C.c_void_p), ("n_nodes", C.c_uint32),
+        ("packets", C.c_void_p), ("n_packets", C.c_uint32),
+        ("tris", C.c_void_p), ("n_tris", C.c_uint32),
+        ("materials", C.c_void_p), ("n_materials", C.c_uint32),
+        ("textures", C.POINTER(SrxTexture)), ("n_textures", C.c_uint32),
+        ("suns", C.c_void_p), ("n_suns", C.c_uint32),
+        ("max_generations", C.c_int32), ("monte_carlo_max", C.c_int32), ("monte_carlo_modifier", C.c_float),
+        ("pdf_lookup", C.c_void_p), ("arccos_lookup", C.c_void_p),
+    ]
+
+
+class SrxCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays_processed", "diffuses_cast", "shadows_cast", "nodes", "packets",
+                                           "shadow_nodes", "shadow_packets", "hits", "texels", "pdf_lookups",
+                                           "trace_launches")] + [("trace_ms", C.c_double), ("shadow_launches", C.c_uint64),
+                                                                 ("shadow_ms", C.c_double), ("shade_launches", C.c_uint64),
+                                                                 ("shade_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_LIB = None
+
+
+def lib():
+    """Load libsrx.so; raises SrxError if it has not been built (run `python -m raytracing_amd.build`)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SrxError(f"{LIB_PATH} is missing: build it with `python -m raytracing_amd.build` (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        L.srx_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise SrxError(f"{what}: {lib().srx_last_error().decode()}")

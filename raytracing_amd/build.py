@@ -1,0 +1,43 @@
+"""Builds raytracing_amd/libsrx.so (HIP kernels + C-ABI) for gfx950 with hipcc.
+
+In-tree build: the .so sits next to this file so it travels with the repo snapshot to the GPU box.
+Run `python -m raytracing_amd.build` (or __graft_entry__.build()).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["srx_trace.hip", "srx_shade.hip", "srx_scene.hip", "srx_render.hip", "srx_packager.cpp"]
+OUT = os.path.join(HERE, "libsrx.so")
+# -ffp-contract=off: FMAs only where the kernels say __fmaf_rn (bit parity with the CPU path);
+# denormals are kept (no -fgpu-flush-denormals-to-zero); correctly rounded fp32 divide/sqrt (HIP default).
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared",
+         "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "srx.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [hipcc] + FLAGS + srcs + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,188 @@
+// raytracing_amd/csrc/srx_device.h — device-side layouts and arithmetic for the trace-and-shade path.
+//
+// HBM layouts (all immutable after srx_scene_create):
+//   GNode   256 B = two 128-B lines. Line A: 8 x {min.x, min.y, min.z, max.x}; line B: 8 x
+//           {max.y, max.z, link, 0}; link = (packets_in_leaf << 24) | index, packets==0 => inner child.
+//           One octet (8 adjacent lanes = the reference's 8 AVX lanes, BVH.h:874-881) reads a node with
+//           two dwordx4 loads per lane, each load covering one contiguous 128-B line per octet.
+//   GPacket 384 B = three 128-B lines: 8 x {p1.x,p1.y,p1.z,e1.x} | 8 x {e1.y,e1.z,e2.x,e2.y} |
+//           8 x {e2.z, material, tri_index, 0}; e1 = p1p2, e2 = p1p3 (Primitives.h:127-134).
+//   GTri    160 B = ten 16-B rows with what shading reads of PackagedTri (Primitives.h:62-81).
+// Arithmetic: compiled with -ffp-contract=off; an FMA appears only where the reference has an FMA
+// intrinsic (__fmaf_rn), min/max follow x86 vminps/vmaxps operand order (second operand on NaN).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SRX_MISS_DISTANCE 99999999999999999.f   // Coredefs.cpp:9
+#define SRX_LINK_COUNT_SHIFT 24
+#define SRX_LINK_INDEX_MASK 0x00FFFFFFu
+
+struct GNode { float4 a[8]; float4 b[8]; };
+struct GPacket { float4 a[8]; float4 b[8]; float4 c[8]; };
+struct GTri {
+    float4 r[10];
+    // r0: UV_basis.xy, U_delta.xy      r1: V_delta.xy, material(bits), normal.x
+    // r2: normal.yz, origin_offset.xy  r3: origin_offset.z, n1.xyz
+    // r4: n2.xyz, n3.x                 r5: n3.yz, t1.xy
+    // r6: t1.z, t2.xyz                 r7: t3.xyz, b1.x
+    // r8: b1.yz, b2.xy                 r9: b2.z, b3.xyz
+};
+static_assert(sizeof(GNode) == 256 && sizeof(GPacket) == 384 && sizeof(GTri) == 160, "layout");
+
+struct GMaterial {       // srx_material with texture ids resolved to table slots (-1 = constant)
+    float color[3];     int color_tex;
+    float roughness;    int roughness_tex;
+    float metallic;     int metallic_tex;
+    float specular;     int specular_tex;
+    float emissive[3];  int emissive_tex;
+    float normal[3];    int normal_tex;
+    float transmission; int transmission_tex;
+    float ior;          int ior_tex;
+    int use_normals;
+};
+struct GTexture {        // Texture.h:69-75
+    const uint8_t* data;
+    int res_x, res_y;
+    double U_multiplier, V_multiplier;
+    int normal_transform;
+    int pad;
+};
+struct GSun { float dir[3]; float emission[3]; };
+
+struct GScene {
+    const GNode* nodes;
+    const GPacket* packets;
+    const GTri* tris;
+    const GMaterial* materials;
+    const GTexture* textures;
+    const GSun* suns;
+    const float* pdf_lookup;      // 1024 x 1024
+    const float* arccos_lookup;   // 2048
+    uint32_t n_nodes, n_packets, n_tris, n_materials, n_textures, n_suns;
+    int max_generations;
+    int bounce_count[32];         // int(monte_carlo_max * pow(modifier, g)), host-computed (Core.h:428)
+    int stack_depth;              // LDS entries per octet (worst-case bound of this tree)
+};
+
+// ---- ray / hit / shadow records of the wavefront queues --------------------
+struct GRay {            // 48 B = 3 x 16 B
+    float ox, oy, oz, dx;
+    float dy, dz, cr, cg;         // c = path throughput (product of coefficient/bounce_count, Core.h:594-597)
+    float cb; uint32_t pixel; uint32_t key_lo, key_hi;
+};
+struct GHit { uint32_t material; float t, u, v; int32_t tri_index; };   // = srx_hit
+struct GShadow {         // 32 B
+    float ox, oy, oz; uint32_t pixel_sun;   // pixel | sun index << 24
+    float cr, cg, cb; float pad;
+};
+static_assert(sizeof(GRay) == 48 && sizeof(GHit) == 20 && sizeof(GShadow) == 32, "records");
+
+// ---- exact helpers ---------------------------------------------------------
+__device__ __forceinline__ float mm_min(float a, float b) { return a < b ? a : b; }   // vminps
+__device__ __forceinline__ float mm_max(float a, float b) { return a > b ? a : b; }   // vmaxps
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+struct f3 {
+    float x, y, z;
+    __device__ __forceinline__ f3() : x(0), y(0), z(0) {}
+    __device__ __forceinline__ explicit f3(float s) : x(s), y(s), z(s) {}
+    __device__ __forceinline__ f3(float a, float b, float c) : x(a), y(b), z(c) {}
+};
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return f3(a.x * s, a.y * s, a.z * s); }   // XYZ.cpp:428
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ f3 operator/(f3 a, f3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // XYZ.cpp:279
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {                                                  // XYZ.cpp:292
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float mag3(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ f3 normalize3(f3 v) {                                                    // XYZ.cpp:237
+    float len = mag3(v);
+    return f3(v.x / len, v.y / len, v.z / len);
+}
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }   // std::min
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }   // std::max
+__device__ __forceinline__ float cdot3(f3 a, f3 b) {                                                // XYZ.cpp:282
+    return std_min(1.0f, std_max(0.0f, a.x * b.x + a.y * b.y + a.z * b.z));
+}
+__device__ __forceinline__ f3 reflect3(f3 v, f3 pole) {                                             // XYZ.cpp:178-186
+    float vm = mag3(v), pm = mag3(pole);
+    float mag_ratio = vm / pm;
+    float cosine = dot3(v, pole) / (mag3(v) * mag3(pole));
+    f3 reflection_point = pole * (cosine * mag_ratio);
+    f3 pointing = reflection_point - v;
+    return v + (pointing * 2.0f);
+}
+__device__ __forceinline__ f3 linear_mix3(float c, f3 f, f3 s) {                                    // XYZ.cpp:397
+    float i = 1 - c;
+    return f3(f.x * i + s.x * c, f.y * i + s.y * c, f.z * i + s.z * c);
+}
+__device__ __forceinline__ f3 apply_tbn(f3 p, f3 T, f3 B, f3 N) { return p.x * T + p.y * B + p.z * N; }   // Matrix.h:62
+__device__ __forceinline__ f3 apply_rotation(f3 p, float qx, float qy, float qz, float qw) {       // XYZ.cpp:679-683
+    f3 r(qx, qy, qz);
+    f3 t = 2.0f * cross3(r, p);
+    return p + qw * t + cross3(r, t);
+}
+__device__ __forceinline__ bool well_defined(float x) { return (f2u(x) & 0x7f800000u) != 0x7f800000u; }   // XYZ.cpp:321
+
+// ---- polynomial trig (VecLib.cpp:23-39,186-223,250-267) ---------------------
+#define SRX_FPI 3.14159265358979323846264f
+#define SRX_PI 3.14159265358979323846264
+__device__ __forceinline__ float full_sin(float x) {
+    float y = SRX_FPI - x;
+    float y2 = y * y;
+    float v = __fmaf_rn(y2, -1.926853e-08f, 2.666575e-06f);
+    v = __fmaf_rn(v, y2, -0.0001977116f);
+    v = __fmaf_rn(v, y2, 0.008330478f);
+    v = __fmaf_rn(v, y2, -0.1666613f);
+    y2 = __fmaf_rn(v, y2, 0.9999967f);
+    return y * y2;
+}
+__device__ __forceinline__ float full_cos(float x) {
+    float y = x - SRX_FPI;
+    y = y * y;
+    float v = __fmaf_rn(y, -1.7094536e-09f, 2.7113737e-07f);
+    v = __fmaf_rn(v, y, -2.478466e-05f);
+    v = __fmaf_rn(v, y, 0.001388931f);
+    v = __fmaf_rn(v, y, -0.04166709f);
+    v = __fmaf_rn(v, y, 0.5000007f);
+    return __fmaf_rn(y, v, -1.0000001f);
+}
+__device__ __forceinline__ float vtan(float x) { return full_sin(x + SRX_FPI) / full_cos(x + SRX_FPI); }
+
+// ---- keyed RNG: one splitmix64 counter per ray -------------------------------
+// Float conversions are the reference's (XorRandom.cpp:37-46 pool halves, :119-121 scalars); the
+// seeding is this renderer's own (the reference seeds worker threads from the clock, SceneManager.h:122).
+struct KeyedGen {
+    uint64_t s;
+    float pool[8];
+    __device__ __forceinline__ static uint64_t mix(uint64_t z) {
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    __device__ __forceinline__ uint64_t next64() { s += 0x9E3779B97F4A7C15ull; return mix(s); }
+    __device__ __forceinline__ static uint64_t primary_key(uint64_t seed, uint64_t sample_index) {
+        return mix(seed ^ mix(sample_index + 0x632BE59BD9B4E019ull));
+    }
+    __device__ __forceinline__ uint64_t child_key() const { return mix(s ^ 0xD1B54A32D192ED03ull); }
+    __device__ __forceinline__ void regen_pool() {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t r = next64();
+            pool[2 * j] = u2f(((uint32_t)r & 0x007fffffu) | 0x3f800000u) - 1.0f;
+            pool[2 * j + 1] = u2f(((uint32_t)(r >> 32) & 0x007fffffu) | 0x3f800000u) - 1.0f;
+        }
+    }
+    __device__ __forceinline__ float fRand(float lo, float hi) {
+        float f = (float)((double)(next64() >> 11) * 0x1.0p-53);
+        return lo + f * (hi - lo);
+    }
+};

@@ -1,0 +1,261 @@
+// raytracing_amd/csrc/srx_scene.hip — C-ABI: device selection, scene upload, batched casts.
+//
+// srx_scene_create replaces RayEngine::load_scene (Core.h:46-48): the reference keeps a pointer to a
+// host PackagedScene (Scene.h:18-31); here the three flat arrays are deep-copied and re-laid for
+// 128-byte coalesced fetches (layouts in srx_device.h), textures/materials/lights/tables uploaded,
+// and the worst-case traversal stack depth of the tree computed so kernels can size their LDS stack.
+#include "srx_host.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+static thread_local std::string g_error;
+void srx_set_error(const std::string& s) { g_error = s; }
+
+extern "C" const char* srx_last_error(void) { return g_error.c_str(); }
+
+extern "C" int srx_init(int device) {
+    int n = 0;
+    SRX_HIP(hipGetDeviceCount(&n));
+    if (n == 0) SRX_FAIL("srx_init: no HIP device visible; this library has no CPU path");
+    if (device < 0 || device >= n) SRX_FAIL("srx_init: device index out of range");
+    SRX_HIP(hipSetDevice(device));
+    hipDeviceProp_t p;
+    SRX_HIP(hipGetDeviceProperties(&p, device));
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        SRX_FAIL(std::string("srx_init: kernels are built for gfx950 only, device is ") + p.gcnArchName);
+    return 0;
+}
+
+namespace {
+
+template <class T>
+int upload(srx_scene* s, const T* host, size_t count, const T** out) {
+    void* d = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    SRX_HIP(hipMalloc(&d, bytes));
+    s->allocations.push_back(d);
+    if (count) SRX_HIP(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return 0;
+}
+
+inline float rdf(const uint8_t* p, size_t off) { float f; std::memcpy(&f, p + off, 4); return f; }
+inline uint32_t rdu(const uint8_t* p, size_t off) { uint32_t u; std::memcpy(&u, p + off, 4); return u; }
+inline float u2f_host(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+// Worst-case number of live stack entries while traversing the tree: visiting a node with m used child
+// slots pops 1 entry and pushes at most m; the deepest subtree may be entered first, with the other
+// m-1 siblings still below it.
+int stack_bound(const uint8_t* nodes, uint32_t n_nodes) {
+    std::vector<int> D(n_nodes, 1);
+    for (int64_t i = (int64_t)n_nodes - 1; i >= 0; i--) {
+        const uint8_t* nd = nodes + (size_t)i * SRX_REF_NODE_BYTES;
+        int m = 0, deepest = 0;
+        for (int k = 0; k < 8; k++) {
+            const uint32_t leaf = rdu(nd, 192 + 4 * k), idx = rdu(nd, 224 + 4 * k);
+            if (leaf == 0 && idx == 0) continue;          // unused slot (BVH.h:890-895)
+            m++;
+            int d = 1;
+            if (leaf == 0) d = (idx > (uint32_t)i && idx < n_nodes) ? D[idx] : 1;
+            deepest = std::max(deepest, d);
+        }
+        D[i] = std::max(1, (m - 1) + deepest);
+    }
+    return n_nodes ? D[0] : 1;
+}
+
+}  // namespace
+
+extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
+    if (!desc || !out) SRX_FAIL("srx_scene_create: null argument");
+    if (desc->n_nodes == 0 || !desc->nodes) SRX_FAIL("srx_scene_create: scene has no BVH nodes");
+    if (desc->n_nodes > SRX_LINK_INDEX_MASK || desc->n_packets > SRX_LINK_INDEX_MASK)
+        SRX_FAIL("srx_scene_create: more than 2^24-1 nodes or packets is not supported");
+    if (desc->max_generations < 0 || desc->max_generations >= 32) SRX_FAIL("srx_scene_create: max_generations must be in [0, 31]");
+    srx_scene* s = new srx_scene();
+    SRX_HIP(hipGetDevice(&s->device));
+    std::memset(&s->g, 0, sizeof(GScene));
+    GScene& g = s->g;
+    const uint8_t* rn = (const uint8_t*)desc->nodes;
+    const uint8_t* rp = (const uint8_t*)desc->packets;
+    const uint8_t* rt = (const uint8_t*)desc->tris;
+
+    // ---- nodes: 288-B SoA record (BVH.h:874-881) -> two 128-B child-major lines
+    std::vector<GNode> nodes(desc->n_nodes);
+    for (uint32_t i = 0; i < desc->n_nodes; i++) {
+        const uint8_t* nd = rn + (size_t)i * SRX_REF_NODE_BYTES;
+        for (int k = 0; k < 8; k++) {
+            const uint32_t leaf = rdu(nd, 192 + 4 * k), idx = rdu(nd, 224 + 4 * k);
+            if (leaf > 255u) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: a leaf with more than 255 packets is not supported"); }
+            if (idx > SRX_LINK_INDEX_MASK || (leaf == 0 && idx >= desc->n_nodes) || (leaf > 0 && idx + leaf > desc->n_packets)) {
+                srx_scene_destroy(s); SRX_FAIL("srx_scene_create: node child index out of range");
+            }
+            nodes[i].a[k] = make_float4(rdf(nd, 96 + 4 * k), rdf(nd, 128 + 4 * k), rdf(nd, 160 + 4 * k), rdf(nd, 0 + 4 * k));
+            nodes[i].b[k] = make_float4(rdf(nd, 32 + 4 * k), rdf(nd, 64 + 4 * k), u2f_host((leaf << SRX_LINK_COUNT_SHIFT) | idx), 0.0f);
+        }
+    }
+    // ---- packets: 448-B record (Primitives.h:127-134) -> three 128-B lanes-major lines
+    std::vector<GPacket> packets(desc->n_packets);
+    for (uint32_t i = 0; i < desc->n_packets; i++) {
+        const uint8_t* pk = rp + (size_t)i * SRX_REF_PACKET_BYTES;
+        const int32_t index = (int32_t)rdu(pk, 416);
+        for (int k = 0; k < 8; k++) {
+            const float p1x = rdf(pk, 0 + 4 * k), p1y = rdf(pk, 32 + 4 * k), p1z = rdf(pk, 64 + 4 * k);
+            const float e1x = rdf(pk, 96 + 4 * k), e1y = rdf(pk, 128 + 4 * k), e1z = rdf(pk, 160 + 4 * k);
+            const float e2x = rdf(pk, 192 + 4 * k), e2y = rdf(pk, 224 + 4 * k), e2z = rdf(pk, 256 + 4 * k);
+            packets[i].a[k] = make_float4(p1x, p1y, p1z, e1x);
+            packets[i].b[k] = make_float4(e1y, e1z, e2x, e2y);
+            packets[i].c[k] = make_float4(e2z, u2f_host(rdu(pk, 384 + 4 * k)), u2f_host((uint32_t)(index + k)), 0.0f);
+        }
+    }
+    // ---- shading triangles: the 160 bytes of PackagedTri (Primitives.h:62-81) that process_ray reads
+    std::vector<GTri> tris(desc->n_tris);
+    for (uint32_t i = 0; i < desc->n_tris; i++) {
+        const uint8_t* t = rt + (size_t)i * SRX_REF_TRI_BYTES;
+        float f[40];
+        int w = 0;
+        for (int k = 0; k < 6; k++) f[w++] = rdf(t, 36 + 4 * k);     // UV_basis, U_delta, V_delta
+        f[w++] = rdf(t, 60);                                         // material (bits)
+        for (int k = 0; k < 33; k++) f[w++] = rdf(t, 64 + 4 * k);    // normal, origin_offset, n1..3, t1..3, b1..3
+        std::memcpy(&tris[i], f, sizeof(GTri));
+        const uint32_t mat = rdu(t, 60);
+        if (mat != 0xFFFFFFFFu && mat >= desc->n_materials && desc->n_materials > 0) {
+            srx_scene_destroy(s); SRX_FAIL("srx_scene_create: triangle material index out of range");
+        }
+    }
+    if (upload(s, nodes.data(), nodes.size(), &g.nodes)) { srx_scene_destroy(s); return 1; }
+    if (upload(s, packets.data(), packets.size(), &g.packets)) { srx_scene_destroy(s); return 1; }
+    if (upload(s, tris.data(), tris.size(), &g.tris)) { srx_scene_destroy(s); return 1; }
+    g.n_nodes = desc->n_nodes; g.n_packets = desc->n_packets; g.n_tris = desc->n_tris;
+
+    // ---- textures (Texture.h:227-230: U_multiplier = resolution * scale, int*float -> float -> double)
+    std::vector<GTexture> tex(desc->n_textures);
+    for (uint32_t i = 0; i < desc->n_textures; i++) {
+        const srx_texture& t = desc->textures[i];
+        if (!t.rgb8 || t.width <= 0 || t.height <= 0) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: bad texture"); }
+        const uint8_t* d = nullptr;
+        if (upload(s, t.rgb8, (size_t)t.width * t.height * 3, &d)) { srx_scene_destroy(s); return 1; }
+        tex[i].data = d; tex[i].res_x = t.width; tex[i].res_y = t.height;
+        tex[i].U_multiplier = (double)(float)(t.width * t.scale_x);
+        tex[i].V_multiplier = (double)(float)(t.height * t.scale_y);
+        tex[i].normal_transform = t.normal_transform; tex[i].pad = 0;
+    }
+    if (upload(s, tex.data(), tex.size(), &g.textures)) { srx_scene_destroy(s); return 1; }
+    g.n_textures = desc->n_textures;
+
+    static_assert(sizeof(GMaterial) == sizeof(srx_material), "material layout");
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        const srx_material& m = desc->materials[i];
+        const int ids[8] = {m.color_tex, m.roughness_tex, m.metallic_tex, m.specular_tex, m.emissive_tex, m.normal_tex, m.transmission_tex, m.ior_tex};
+        for (int id : ids) if (id >= (int)desc->n_textures) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: material texture id out of range"); }
+    }
+    if (upload(s, (const GMaterial*)desc->materials, desc->n_materials, &g.materials)) { srx_scene_destroy(s); return 1; }
+    g.n_materials = desc->n_materials;
+    static_assert(sizeof(GSun) == sizeof(srx_sun), "sun layout");
+    if (desc->n_suns > 255) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: at most 255 sun lights"); }
+    if (upload(s, (const GSun*)desc->suns, desc->n_suns, &g.suns)) { srx_scene_destroy(s); return 1; }
+    g.n_suns = desc->n_suns;
+
+    // ---- lookup tables
+    std::vector<float> arccos, pdf;
+    const float* pa = desc->arccos_lookup; const float* pp = desc->pdf_lookup;
+    if (!pa || !pp) {
+        arccos.resize(2048); pdf.resize(1024 * 1024);
+        if (srx_build_tables(arccos.data(), pdf.data())) { srx_scene_destroy(s); return 1; }
+        if (!pa) pa = arccos.data();
+        if (!pp) pp = pdf.data();
+    }
+    if (upload(s, pa, 2048, &g.arccos_lookup)) { srx_scene_destroy(s); return 1; }
+    if (upload(s, pp, (size_t)1024 * 1024, &g.pdf_lookup)) { srx_scene_destroy(s); return 1; }
+
+    g.max_generations = desc->max_generations;
+    for (int gen = 0; gen < 32; gen++) {   // Core.h:428: int = short * pow(float, char) in double
+        double v = (double)(short)desc->monte_carlo_max * std::pow((double)desc->monte_carlo_modifier, (double)gen);
+        g.bounce_count[gen] = (int)v;
+    }
+    const int bound = stack_bound(rn, desc->n_nodes);
+    if (bound > 256) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: tree needs a traversal stack deeper than the reference's 256 entries (Scene.h:181)"); }
+    g.stack_depth = std::max(bound, 2);
+    *out = s;
+    return 0;
+}
+
+extern "C" void srx_scene_destroy(srx_scene* scene) {
+    if (!scene) return;
+    for (void* p : scene->allocations) (void)hipFree(p);
+    delete scene;
+}
+
+extern "C" int srx_scene_stack_bound(const srx_scene* scene) { return scene ? scene->g.stack_depth : -1; }
+
+// ---------------------------------------------------------------- casts
+extern "C" int srx_cast_closest_device(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, srx_hit* d_hits,
+                                       uint64_t* d_counters2, void* stream) {
+    if (!scene) SRX_FAIL("srx_cast_closest_device: null scene");
+    TraceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.org = d_org3; a.org_stride = 3; a.dir = d_dir3; a.dir_stride = 3; a.n = n;
+    a.hits = (GHit*)d_hits;
+    a.counters = (unsigned long long*)d_counters2;
+    SRX_HIP(srx_launch_trace(0, scene->g, a, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int srx_cast_shadow_device(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, uint8_t* d_lit, void* stream) {
+    if (!scene) SRX_FAIL("srx_cast_shadow_device: null scene");
+    TraceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.org = d_org3; a.org_stride = 3; a.dir = d_dir3; a.dir_stride = 3; a.n = n;
+    a.lit = d_lit;
+    SRX_HIP(srx_launch_trace(1, scene->g, a, (hipStream_t)stream));
+    return 0;
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+extern "C" int srx_cast_closest(srx_scene* scene, const float* org3, const float* dir3, uint32_t n, srx_hit* hits,
+                                float* advanced_org3, uint64_t* counters2) {
+    if (!scene) SRX_FAIL("srx_cast_closest: null scene");
+    if (n == 0) { if (counters2) counters2[0] = counters2[1] = 0; return 0; }
+    DevBuf o, d, h, adv, c;
+    SRX_HIP(hipMalloc(&o.p, (size_t)n * 12)); SRX_HIP(hipMalloc(&d.p, (size_t)n * 12));
+    SRX_HIP(hipMalloc(&h.p, (size_t)n * sizeof(srx_hit)));
+    SRX_HIP(hipMalloc(&c.p, 16));
+    if (advanced_org3) SRX_HIP(hipMalloc(&adv.p, (size_t)n * 12));
+    SRX_HIP(hipMemcpy(o.p, org3, (size_t)n * 12, hipMemcpyHostToDevice));
+    SRX_HIP(hipMemcpy(d.p, dir3, (size_t)n * 12, hipMemcpyHostToDevice));
+    SRX_HIP(hipMemset(c.p, 0, 16));
+    TraceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.org = (const float*)o.p; a.org_stride = 3; a.dir = (const float*)d.p; a.dir_stride = 3; a.n = n;
+    a.hits = (GHit*)h.p; a.advanced_org3 = (float*)adv.p; a.counters = (unsigned long long*)c.p;
+    SRX_HIP(srx_launch_trace(0, scene->g, a, 0));
+    SRX_HIP(hipDeviceSynchronize());
+    SRX_HIP(hipMemcpy(hits, h.p, (size_t)n * sizeof(srx_hit), hipMemcpyDeviceToHost));
+    if (advanced_org3) SRX_HIP(hipMemcpy(advanced_org3, adv.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    if (counters2) SRX_HIP(hipMemcpy(counters2, c.p, 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int srx_cast_shadow(srx_scene* scene, const float* org3, const float* dir3, uint32_t n, uint8_t* lit) {
+    if (!scene) SRX_FAIL("srx_cast_shadow: null scene");
+    if (n == 0) return 0;
+    DevBuf o, d, l;
+    SRX_HIP(hipMalloc(&o.p, (size_t)n * 12)); SRX_HIP(hipMalloc(&d.p, (size_t)n * 12)); SRX_HIP(hipMalloc(&l.p, n));
+    SRX_HIP(hipMemcpy(o.p, org3, (size_t)n * 12, hipMemcpyHostToDevice));
+    SRX_HIP(hipMemcpy(d.p, dir3, (size_t)n * 12, hipMemcpyHostToDevice));
+    TraceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.org = (const float*)o.p; a.org_stride = 3; a.dir = (const float*)d.p; a.dir_stride = 3; a.n = n;
+    a.lit = (uint8_t*)l.p;
+    SRX_HIP(srx_launch_trace(1, scene->g, a, 0));
+    SRX_HIP(hipDeviceSynchronize());
+    SRX_HIP(hipMemcpy(lit, l.p, n, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -294,57 +294,63 @@ def atrium(n_tris=262144, res=(1920, 1080), subdiv=8, max_generations=8, seed=7,
     W, L, H = 6.0, 30.0, 10.0     # half-width, half-length, height; floor at z=-1.5 (origin is inside the hall)
     z0 = -1.5
     J = 2e-3
-    parts = []
-    budget = n_tris
+    rng_state = rng.bit_generator.state
+    # scale tessellation with the requested size (n_tris=262144 -> s=1); shrink until the base fits
+    s = max(0.02, math.sqrt(n_tris / 262144.0))
+    while True:
+        rng.bit_generator.state = rng_state
+        parts = []
+        budget = n_tris
 
-    def add(t):
-        nonlocal budget
-        parts.append(t)
-        budget -= len(t)
+        def add(t):
+            nonlocal budget
+            parts.append(t)
+            budget -= len(t)
 
-    # scale tessellation with the requested size (n_tris=262144 -> s=1)
-    s = max(0.05, math.sqrt(n_tris / 262144.0))
-    g = lambda n: max(1, int(round(n * s)))
-    add(grid_mesh((-W, -L, z0), (2 * W, 0, 0), (0, 2 * L, 0), g(64), g(320), 1, rng, J, uv_scale=12))       # floor
-    add(grid_mesh((-W, -L, z0), (0, 2 * L, 0), (0, 0, H), g(320), g(48), 0, rng, J, uv_scale=10))           # left wall
-    add(grid_mesh((W, -L, z0), (0, 2 * L, 0), (0, 0, H), g(320), g(48), 0, rng, J, uv_scale=10))            # right wall
-    add(grid_mesh((-W, L, z0), (2 * W, 0, 0), (0, 0, H), g(64), g(48), 7, rng, J, uv_scale=4))              # far wall
-    add(grid_mesh((-W, -L, z0), (2 * W, 0, 0), (0, 0, H), g(64), g(48), 7, rng, J, uv_scale=4))             # near wall
-    # roof: two strips leaving a slot open along the hall
-    add(grid_mesh((-W, -L, z0 + H), (W - 1.5, 0, 0), (0, 2 * L, 0), g(24), g(160), 9, rng, J))
-    add(grid_mesh((1.5, -L, z0 + H), (W - 1.5, 0, 0), (0, 2 * L, 0), g(24), g(160), 9, rng, J))
-    # galleries (upper floors along both sides)
-    add(grid_mesh((-W, -L, z0 + 4.5), (2.0, 0, 0), (0, 2 * L, 0), g(12), g(160), 10, rng, J, uv_scale=8))
-    add(grid_mesh((W - 2.0, -L, z0 + 4.5), (2.0, 0, 0), (0, 2 * L, 0), g(12), g(160), 10, rng, J, uv_scale=8))
-    # colonnades
-    ncol = 14
-    for side in (-1, 1):
-        for i in range(ncol):
-            y = -L + (i + 0.5) * (2 * L / ncol)
-            add(cylinder_mesh((side * (W - 2.2), y, z0), 0.35, 4.5, g(48), g(24), 2, rng, 1e-3, uv_scale=2))
-            add(cylinder_mesh((side * (W - 2.2), y, z0 + 4.5), 0.25, 5.5, g(32), g(16), 11, rng, 1e-3))
-    # banners hanging in the slot
-    for i in range(10):
-        y = -L + (i + 0.5) * (2 * L / 10)
-        m = 3 if i % 2 == 0 else 4
-        add(grid_mesh((-1.2, y, z0 + 4.0), (2.4, 0, 0.15), (0, 0.05, 4.5), g(24), g(40), m, rng, 4e-3))
-    # vases / spheres on the floor
-    for i in range(16):
-        y = -L + (i + 0.5) * (2 * L / 16)
-        x = (-1) ** i * 2.0
-        add(sphere_mesh((x, y, z0 + 0.45), 0.45, g(40), g(24), 5 if i % 3 else 6))
-    # blue tiled pool rim boxes
-    for i in range(6):
-        y = -L + (i + 0.5) * (2 * L / 6)
-        add(box_mesh((0.0, y, z0 + 0.15), (0.9, 1.5, 0.15), 8, rot_z=0.05 * i))
-    if budget < 0:
-        raise ValueError(f"atrium base geometry ({n_tris - budget}) exceeds n_tris={n_tris}")
+        g = lambda n: max(1, int(round(n * s)))
+        add(grid_mesh((-W, -L, z0), (2 * W, 0, 0), (0, 2 * L, 0), g(64), g(320), 1, rng, J, uv_scale=12))       # floor
+        add(grid_mesh((-W, -L, z0), (0, 2 * L, 0), (0, 0, H), g(320), g(48), 0, rng, J, uv_scale=10))           # left wall
+        add(grid_mesh((W, -L, z0), (0, 2 * L, 0), (0, 0, H), g(320), g(48), 0, rng, J, uv_scale=10))            # right wall
+        add(grid_mesh((-W, L, z0), (2 * W, 0, 0), (0, 0, H), g(64), g(48), 7, rng, J, uv_scale=4))              # far wall
+        add(grid_mesh((-W, -L, z0), (2 * W, 0, 0), (0, 0, H), g(64), g(48), 7, rng, J, uv_scale=4))             # near wall
+        # roof: two strips leaving a slot open along the hall
+        add(grid_mesh((-W, -L, z0 + H), (W - 1.5, 0, 0), (0, 2 * L, 0), g(24), g(160), 9, rng, J))
+        add(grid_mesh((1.5, -L, z0 + H), (W - 1.5, 0, 0), (0, 2 * L, 0), g(24), g(160), 9, rng, J))
+        # galleries (upper floors along both sides)
+        add(grid_mesh((-W, -L, z0 + 4.5), (2.0, 0, 0), (0, 2 * L, 0), g(12), g(160), 10, rng, J, uv_scale=8))
+        add(grid_mesh((W - 2.0, -L, z0 + 4.5), (2.0, 0, 0), (0, 2 * L, 0), g(12), g(160), 10, rng, J, uv_scale=8))
+        # colonnades
+        ncol = 14
+        for side in (-1, 1):
+            for i in range(ncol):
+                y = -L + (i + 0.5) * (2 * L / ncol)
+                add(cylinder_mesh((side * (W - 2.2), y, z0), 0.35, 4.5, max(3, g(48)), g(24), 2, rng, 1e-3, uv_scale=2))
+                add(cylinder_mesh((side * (W - 2.2), y, z0 + 4.5), 0.25, 5.5, max(3, g(32)), g(16), 11, rng, 1e-3))
+        # banners hanging in the slot
+        for i in range(10):
+            y = -L + (i + 0.5) * (2 * L / 10)
+            m = 3 if i % 2 == 0 else 4
+            add(grid_mesh((-1.2, y, z0 + 4.0), (2.4, 0, 0.15), (0, 0.05, 4.5), g(24), g(40), m, rng, 4e-3))
+        # vases / spheres on the floor
+        for i in range(16):
+            y = -L + (i + 0.5) * (2 * L / 16)
+            x = (-1) ** i * 2.0
+            add(sphere_mesh((x, y, z0 + 0.45), 0.45, max(3, g(40)), max(2, g(24)), 5 if i % 3 else 6))
+        # blue tiled pool rim boxes
+        for i in range(6):
+            y = -L + (i + 0.5) * (2 * L / 6)
+            add(box_mesh((0.0, y, z0 + 0.15), (0.9, 1.5, 0.15), 8, rot_z=0.05 * i))
+        if budget >= 0:
+            break
+        s *= 0.9
+        if s < 1e-3:
+            raise ValueError(f"atrium base geometry does not fit n_tris={n_tris}")
     # fill the remaining budget with clutter spheres on the galleries, then trim to the exact count
     k = 0
     while budget > 0:
         side = -1 if k % 2 == 0 else 1
         y = -L + 1.0 + ((k // 2) * 1.7) % (2 * L - 2.0)
-        nseg, nrow = g(32), g(20)
+        nseg, nrow = max(3, g(32)), max(2, g(20))
         t = sphere_mesh((side * (W - 1.0), y, z0 + 4.5 + 0.3 + 0.002 * k), 0.3, nseg, nrow, 5 + (k % 7))
         if len(t) > budget:
             t = t[:budget]
