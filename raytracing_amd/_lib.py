@@ -63,6 +63,12 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise SrxError(f"{LIB_PATH} is missing: build it with `python -m raytracing_amd.build` (no CPU fallback exists)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; loading it first makes
+        # libsrx.so bind to the same runtime, so device pointers and streams can be shared with torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.srx_last_error.restype = C.c_char_p
         _LIB = L

@@ -16,3 +16,31 @@ struct TraceArgs {
 
 // mode 0: closest hit; 1: shadow (API form, writes lit[]); 2: shadow (renderer queue form, adds lit contributions)
 extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& a, hipStream_t stream);
+
+// == srx_camera (include/srx.h), Camera.h:32-140
+struct GCamera {
+    float pos[3]; float rot[4]; float focal[3];
+    float lens_width, lens_height;
+    int res_x, res_y, subdiv;
+};
+
+struct ShadeArgs {
+    const GRay* rays;              // queue segment being shaded
+    const GHit* hits;              // hit record of each ray of the segment
+    uint32_t n;
+    int generation;                // PackagedRay::generation of every ray in the segment (Ray.h:10)
+    GRay* out_rays;                // next generation's rays are appended here ...
+    uint32_t* out_count;           // ... at *out_count (device counter, one atomic per wave)
+    GShadow* shadow_q;             // shadow rays of this segment (one per hit and sun light)
+    uint32_t* shadow_count;
+    float* sample3;                // per-pixel sample sums (float atomics)
+    unsigned long long* counters;  // [4] hits, [5] texels, [6] pdf lookups, [7] children
+};
+
+extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hipStream_t stream);
+extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int y0, int w, int h, uint32_t pass_index, uint64_t seed,
+                                        GRay* rays, float* dir3, unsigned long long* keys, hipStream_t stream);
+extern "C" hipError_t srx_launch_pack_rays(const float* org3, const float* dir3, const unsigned long long* keys, uint32_t n,
+                                           GRay* rays, hipStream_t stream);
+extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int y0, int w, int h, uint32_t pass_index, float* sample3,
+                                            float* accum4, float* aux4, hipStream_t stream);

@@ -1,0 +1,285 @@
+// raytracing_amd/csrc/srx_render.hip — C-ABI: wavefront renderer (host scheduler over the kernels).
+//
+// Replaces the loop around RayEngine::process_ray in RenderThread::process_iteratively
+// (SceneManager.h:193-237) and the recursion inside process_ray (Core.h:592-598).
+//
+// Queue memory is one device array of `ray_capacity` 48-byte ray slots used as a STACK of segments:
+// a segment [begin,end) of generation g is traced and shaded in batches; the children of a batch are
+// appended above the current top and processed (depth first) before the next batch, then popped. A
+// batch is sized so that its worst-case fan-out (bounce_count[g] children per ray, Core.h:428) fits in
+// the free slots, so nothing is ever dropped and small capacities only mean more, smaller launches.
+// Per batch: trace kernel -> shade kernel (appends children + shadow rays, one atomic per wave) ->
+// 8-byte count readback -> shadow kernel (adds lit direct-light contributions to the sample buffer).
+#include "srx_host.h"
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+enum { CTR_NODES = 0, CTR_PACKETS = 1, CTR_SNODES = 2, CTR_SPACKETS = 3, CTR_HITS = 4, CTR_TEXELS = 5, CTR_PDF = 6,
+       CTR_CHILDREN = 7, CTR_COUNT = 8 };
+
+struct DeviceCounts { uint32_t out_count, shadow_count; };
+
+}  // namespace
+
+struct srx_renderer {
+    srx_scene* scene = nullptr;
+    uint64_t capacity = 0;            // ray slots
+    uint64_t shadow_capacity = 0;
+    GRay* rays = nullptr;
+    GHit* hits = nullptr;
+    GShadow* shadow_q = nullptr;
+    DeviceCounts* d_counts = nullptr;
+    unsigned long long* d_counters = nullptr;
+    float* sample3 = nullptr;         // per-pixel sample sums
+    uint64_t sample_pixels = 0;
+    hipStream_t stream = nullptr;
+    DeviceCounts* h_counts = nullptr; // pinned
+    bool timing = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // per-call accumulators
+    uint64_t top = 0;
+    srx_counters acc;
+};
+
+extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_renderer** out) {
+    if (!scene || !out) SRX_FAIL("srx_renderer_create: null argument");
+    if (ray_capacity < 64) SRX_FAIL("srx_renderer_create: ray_capacity must be at least 64");
+    if (ray_capacity > 0xFFFFFFF0ull) SRX_FAIL("srx_renderer_create: ray_capacity must fit 32 bits");
+    srx_renderer* r = new srx_renderer();
+    r->scene = scene;
+    r->capacity = ray_capacity;
+    r->shadow_capacity = ray_capacity;
+    std::memset(&r->acc, 0, sizeof(r->acc));
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    chk(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    chk(hipMalloc((void**)&r->rays, ray_capacity * sizeof(GRay)));
+    chk(hipMalloc((void**)&r->hits, ray_capacity * sizeof(GHit)));
+    chk(hipMalloc((void**)&r->shadow_q, r->shadow_capacity * sizeof(GShadow)));
+    chk(hipMalloc((void**)&r->d_counts, sizeof(DeviceCounts)));
+    chk(hipMalloc((void**)&r->d_counters, CTR_COUNT * sizeof(unsigned long long)));
+    chk(hipHostMalloc((void**)&r->h_counts, sizeof(DeviceCounts)));
+    for (int i = 0; i < 6; i++) chk(hipEventCreate(&r->ev[i]));
+    if (e != hipSuccess) {
+        srx_set_error(std::string("srx_renderer_create: ") + hipGetErrorString(e));
+        srx_renderer_destroy(r);
+        return 1;
+    }
+    *out = r;
+    return 0;
+}
+
+extern "C" void srx_renderer_destroy(srx_renderer* r) {
+    if (!r) return;
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    (void)hipFree(r->rays); (void)hipFree(r->hits); (void)hipFree(r->shadow_q);
+    (void)hipFree(r->d_counts); (void)hipFree(r->d_counters); (void)hipFree(r->sample3);
+    if (r->h_counts) (void)hipHostFree(r->h_counts);
+    for (int i = 0; i < 6; i++) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+extern "C" int srx_renderer_set_timing(srx_renderer* r, int enabled) {
+    if (!r) SRX_FAIL("srx_renderer_set_timing: null renderer");
+    r->timing = enabled != 0;
+    return 0;
+}
+
+namespace {
+
+int ensure_sample_buffer(srx_renderer* r, uint64_t pixels) {
+    if (r->sample_pixels >= pixels) return 0;
+    if (r->sample3) { SRX_HIP(hipStreamSynchronize(r->stream)); SRX_HIP(hipFree(r->sample3)); r->sample3 = nullptr; }
+    SRX_HIP(hipMalloc((void**)&r->sample3, pixels * 3 * sizeof(float)));
+    SRX_HIP(hipMemsetAsync(r->sample3, 0, pixels * 3 * sizeof(float), r->stream));
+    r->sample_pixels = pixels;
+    return 0;
+}
+
+// Process the queue segment [begin, end) of generation `gen`; children go above r->top.
+int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
+    const GScene& g = r->scene->g;
+    const bool spawns = gen < g.max_generations;                        // Core.h:473
+    const uint64_t fan = spawns ? (uint64_t)std::max(1, g.bounce_count[gen]) : 0;
+    while (begin < end) {
+        uint64_t n = end - begin;
+        if (fan) {
+            // keep `reserve` slots back so every deeper generation can still process at least one ray at a time
+            uint64_t reserve = 0;
+            for (int d = gen + 1; d < g.max_generations; d++) reserve += (uint64_t)std::max(1, g.bounce_count[d]);
+            const uint64_t free_slots = r->capacity - r->top;
+            n = std::min(n, free_slots > reserve ? (free_slots - reserve) / fan : 0);
+            if (n == 0) SRX_FAIL("srx: ray_capacity too small for one ray's fan-out at this generation; create the renderer with more slots");
+        }
+        if (g.n_suns) n = std::min(n, r->shadow_capacity / g.n_suns);
+        if (n == 0) SRX_FAIL("srx: shadow queue too small");
+
+        // ---- closest hit
+        TraceArgs t;
+        std::memset(&t, 0, sizeof(t));
+        t.org = &r->rays[begin].ox; t.org_stride = sizeof(GRay) / 4;
+        t.dir = &r->rays[begin].dx; t.dir_stride = sizeof(GRay) / 4;
+        t.n = (uint32_t)n;
+        t.hits = r->hits;
+        t.counters = r->d_counters + CTR_NODES;
+        if (r->timing) SRX_HIP(hipEventRecord(r->ev[0], r->stream));
+        SRX_HIP(srx_launch_trace(0, g, t, r->stream));
+        if (r->timing) SRX_HIP(hipEventRecord(r->ev[1], r->stream));
+
+        // ---- shade + bounce (appends children at top, shadow rays into shadow_q)
+        SRX_HIP(hipMemsetAsync(r->d_counts, 0, sizeof(DeviceCounts), r->stream));
+        ShadeArgs s;
+        std::memset(&s, 0, sizeof(s));
+        s.rays = r->rays + begin; s.hits = r->hits; s.n = (uint32_t)n; s.generation = gen;
+        s.out_rays = r->rays + r->top; s.out_count = &r->d_counts->out_count;
+        s.shadow_q = r->shadow_q; s.shadow_count = &r->d_counts->shadow_count;
+        s.sample3 = r->sample3; s.counters = r->d_counters;
+        if (r->timing) SRX_HIP(hipEventRecord(r->ev[2], r->stream));
+        SRX_HIP(srx_launch_shade(g, s, r->stream));
+        if (r->timing) SRX_HIP(hipEventRecord(r->ev[3], r->stream));
+        SRX_HIP(hipMemcpyAsync(r->h_counts, r->d_counts, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
+        SRX_HIP(hipStreamSynchronize(r->stream));
+        const uint64_t n_children = r->h_counts->out_count, n_shadow = r->h_counts->shadow_count;
+        if (n_children > n * fan || r->top + n_children > r->capacity) SRX_FAIL("srx: internal error, child count exceeds the reserved slots");
+        if (n_shadow > r->shadow_capacity) SRX_FAIL("srx: internal error, shadow count exceeds the queue");
+
+        // ---- shadow rays of this batch: lit ones add their contribution to the sample buffer
+        if (n_shadow) {
+            TraceArgs sh;
+            std::memset(&sh, 0, sizeof(sh));
+            sh.org = &r->shadow_q[0].ox; sh.org_stride = sizeof(GShadow) / 4;
+            sh.n = (uint32_t)n_shadow;
+            sh.shadow_q = r->shadow_q; sh.sample3 = r->sample3;
+            sh.counters = r->d_counters + CTR_SNODES;
+            if (r->timing) SRX_HIP(hipEventRecord(r->ev[4], r->stream));
+            SRX_HIP(srx_launch_trace(2, g, sh, r->stream));
+            if (r->timing) SRX_HIP(hipEventRecord(r->ev[5], r->stream));
+        }
+        r->acc.rays_processed += n;
+        r->acc.shadows_cast += n_shadow;
+        r->acc.trace_launches++; r->acc.shade_launches++;
+        if (n_shadow) r->acc.shadow_launches++;
+        if (r->timing) {
+            float ms = 0;
+            if (n_shadow) { SRX_HIP(hipEventSynchronize(r->ev[5])); SRX_HIP(hipEventElapsedTime(&ms, r->ev[4], r->ev[5])); r->acc.shadow_ms += ms; }
+            SRX_HIP(hipEventElapsedTime(&ms, r->ev[0], r->ev[1])); r->acc.trace_ms += ms;
+            SRX_HIP(hipEventElapsedTime(&ms, r->ev[2], r->ev[3])); r->acc.shade_ms += ms;
+        }
+        // ---- next generation, depth first
+        if (n_children) {
+            const uint64_t old_top = r->top;
+            r->top += n_children;
+            if (process_segment(r, gen + 1, old_top, old_top + n_children)) return 1;
+            r->top = old_top;
+        }
+        begin += n;
+    }
+    return 0;
+}
+
+int begin_call(srx_renderer* r) {
+    std::memset(&r->acc, 0, sizeof(r->acc));
+    SRX_HIP(hipMemsetAsync(r->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), r->stream));
+    return 0;
+}
+
+int end_call(srx_renderer* r, srx_counters* out) {
+    unsigned long long c[CTR_COUNT];
+    SRX_HIP(hipMemcpyAsync(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost, r->stream));
+    SRX_HIP(hipStreamSynchronize(r->stream));
+    r->acc.nodes = c[CTR_NODES]; r->acc.packets = c[CTR_PACKETS];
+    r->acc.shadow_nodes = c[CTR_SNODES]; r->acc.shadow_packets = c[CTR_SPACKETS];
+    r->acc.hits = c[CTR_HITS]; r->acc.texels = c[CTR_TEXELS]; r->acc.pdf_lookups = c[CTR_PDF];
+    r->acc.diffuses_cast = c[CTR_CHILDREN];
+    if (out) *out = r->acc;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int srx_trace_pass(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                              uint32_t pass_index, uint64_t seed, float* d_accum4, float* d_aux4, srx_counters* counters) {
+    if (!r || !camera || !d_accum4) SRX_FAIL("srx_trace_pass: null argument");
+    if (camera->res_x <= 0 || camera->res_y <= 0 || camera->subdiv <= 0) SRX_FAIL("srx_trace_pass: bad camera");
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > camera->res_x || y0 + h > camera->res_y)
+        SRX_FAIL("srx_trace_pass: rectangle outside the camera resolution");
+    const uint64_t npix = (uint64_t)camera->res_x * camera->res_y;
+    if (npix > 0x00FFFFFFull) SRX_FAIL("srx_trace_pass: more than 2^24-1 pixels is not supported");
+    if (ensure_sample_buffer(r, npix)) return 1;
+    if (begin_call(r)) return 1;
+    static_assert(sizeof(GCamera) == sizeof(srx_camera), "camera layout");
+    GCamera cam;
+    std::memcpy(&cam, camera, sizeof(cam));
+    // primaries are generated in row bands that fit the queue with their worst-case fan-out
+    const GScene& g = r->scene->g;
+    const uint64_t fan0 = (uint64_t)std::max(1, g.bounce_count[0]);
+    uint64_t band_rays = r->capacity / (1 + (g.max_generations > 0 ? fan0 : 0));
+    if (band_rays < (uint64_t)w) SRX_FAIL("srx_trace_pass: ray_capacity too small for one pixel row and its first bounce");
+    const int band_rows = (int)std::min<uint64_t>((uint64_t)h, band_rays / (uint64_t)w);
+    for (int yb = y0; yb < y0 + h; yb += band_rows) {
+        const int rows = std::min(band_rows, y0 + h - yb);
+        const uint64_t n = (uint64_t)rows * w;
+        SRX_HIP(srx_launch_raygen(cam, x0, yb, w, rows, pass_index, seed, r->rays, nullptr, nullptr, r->stream));
+        r->top = n;
+        if (process_segment(r, 0, 0, n)) return 1;
+    }
+    SRX_HIP(srx_launch_accumulate(camera->res_x, x0, y0, w, h, pass_index, r->sample3, d_accum4, d_aux4, r->stream));
+    return end_call(r, counters);
+}
+
+extern "C" int srx_process_rays(srx_renderer* r, const float* org3, const float* dir3, const uint64_t* keys, int32_t generation,
+                                uint32_t n, float* radiance3, srx_counters* counters) {
+    if (!r || !org3 || !dir3 || !keys || !radiance3) SRX_FAIL("srx_process_rays: null argument");
+    if (generation < 0 || generation >= 32) SRX_FAIL("srx_process_rays: generation out of range");
+    if (n > 0x00FFFFFFu) SRX_FAIL("srx_process_rays: at most 2^24-1 rays per call");
+    if (begin_call(r)) return 1;
+    if (n == 0) return end_call(r, counters);
+    if (ensure_sample_buffer(r, n)) return 1;
+    const GScene& g = r->scene->g;
+    const uint64_t fan = generation < g.max_generations ? (uint64_t)std::max(1, g.bounce_count[generation]) : 0;
+    const uint64_t chunk = r->capacity / (1 + fan);
+    if (chunk == 0) SRX_FAIL("srx_process_rays: ray_capacity too small");
+    float *d_o = nullptr, *d_d = nullptr; unsigned long long* d_k = nullptr;
+    SRX_HIP(hipMalloc((void**)&d_o, (size_t)n * 12)); SRX_HIP(hipMalloc((void**)&d_d, (size_t)n * 12)); SRX_HIP(hipMalloc((void**)&d_k, (size_t)n * 8));
+    int rc = 0;
+    do {
+        if (hipMemcpy(d_o, org3, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_d, dir3, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_k, keys, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { srx_set_error("srx_process_rays: upload failed"); rc = 1; break; }
+        for (uint64_t b = 0; b < n && !rc; b += chunk) {
+            const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - b);
+            if (srx_launch_pack_rays(d_o + 3 * b, d_d + 3 * b, d_k + b, m, r->rays, r->stream) != hipSuccess) { srx_set_error("srx_process_rays: pack launch failed"); rc = 1; break; }
+            // pixel index of ray i is i within the chunk: shift by the chunk base afterwards
+            r->top = m;
+            if (process_segment(r, generation, 0, m)) { rc = 1; break; }
+            if (hipMemcpyAsync(radiance3 + 3 * b, r->sample3, (size_t)m * 12, hipMemcpyDeviceToHost, r->stream) != hipSuccess ||
+                hipMemsetAsync(r->sample3, 0, (size_t)m * 12, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess) {
+                srx_set_error("srx_process_rays: readback failed"); rc = 1; break;
+            }
+        }
+    } while (0);
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_k);
+    if (rc) return rc;
+    return end_call(r, counters);
+}
+
+extern "C" int srx_camera_rays(const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h, uint32_t pass_index,
+                               uint64_t seed, float* dir3, uint64_t* keys) {
+    if (!camera || !dir3 || !keys) SRX_FAIL("srx_camera_rays: null argument");
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > camera->res_x || y0 + h > camera->res_y)
+        SRX_FAIL("srx_camera_rays: rectangle outside the camera resolution");
+    GCamera cam;
+    std::memcpy(&cam, camera, sizeof(cam));
+    const size_t n = (size_t)w * h;
+    float* d_d = nullptr; unsigned long long* d_k = nullptr;
+    SRX_HIP(hipMalloc((void**)&d_d, n * 12)); SRX_HIP(hipMalloc((void**)&d_k, n * 8));
+    hipError_t e = srx_launch_raygen(cam, x0, y0, w, h, pass_index, seed, nullptr, d_d, d_k, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(dir3, d_d, n * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(keys, d_k, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_d); (void)hipFree(d_k);
+    if (e != hipSuccess) SRX_FAIL(std::string("srx_camera_rays: ") + hipGetErrorString(e));
+    return 0;
+}
