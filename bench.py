@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the trace-and-shade path: Mrays/s at 1080p on the Sponza-class scene.
+
+A "step" is one sample pass (1 spp) of the hot path over the whole 1920x1080 frame of BASELINE.json's
+configs[1] workload (procedural 262,144-triangle atrium, max_generations 8, monte_carlo_max 32): primary
+rays -> closest hit -> shade/bounce -> compaction -> ... until every path has ended, then accumulation.
+Rays = process_ray invocations (primary + every bounce generation), the reference's own count
+(SceneManager.h:83-90); shadow rays are reported beside it. The scene, tables and framebuffers are resident
+in HBM before the timed region starts.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the frame is sharded by horizontal tile
+slabs with the scene replicated (strong scaling, total work fixed); no collective on the data path, one
+framebuffer all-gather over RCCL at the end of the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per unit for the closest-hit kernel, reference record sizes:
+# 288 B per node test, 448 B per packet test, 64 B PackagedRay read + 32 B CastResults write per ray
+NODE_B, PACKET_B, RAY_B, HIT_B = 288, 448, 64, 32
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tris", type=int, default=262144)
+    ap.add_argument("--res", type=str, default="1920x1080")
+    ap.add_argument("--ray-capacity", type=int, default=1 << 27)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="480x270", help="centre crop of the frame timed on the host cores")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=20241111)
+    return ap.parse_args()
+
+
+def cpu_baseline(desc, cam, crop, seed, threads):
+    """Times the CPU restatement (oracle, reference RNG mode, std::thread workers over interleaved rows) on
+    a bounded crop of the same frame. This is the only place bench.py touches oracle/."""
+    from oracle import sro
+    S = sro.OracleScene(desc, build_tables=True)
+    W, H = int(cam["res_x"]), int(cam["res_y"])
+    cw, ch = crop
+    x0, y0 = (W - cw) // 2, (H - ch) // 2
+    acc = np.zeros((W * H, 4), np.float32)
+    # one untimed warm-up on a thin band, then the timed pass
+    S.render_pass(cam, (x0, y0, cw, 4), 0, seed, acc, None, mode=1, threads=threads)
+    t0 = time.perf_counter()
+    st = S.render_pass(cam, (x0, y0, cw, ch), 1, seed, acc, None, mode=1, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": float(st[0]) / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"1 pass over the centre {cw}x{ch} crop of the same frame: {int(st[0])} rays (+{int(st[2])} shadow casts) in {dt:.2f} s",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible and there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raytracing_amd import engine, scenes
+
+    W, H = (int(v) for v in args.res.split("x"))
+    desc = scenes.atrium(args.tris, res=(W, H), subdiv=8, max_generations=8)
+    cam = desc.camera
+    t0 = time.perf_counter()
+    PS = engine.package(desc)
+    t_pack = time.perf_counter() - t0
+    RE = engine.RayEngine(local_rank)
+    RE.load_scene(PS)
+    RE.set_timing(True, ray_capacity=args.ray_capacity)
+
+    # tile slab of this rank (horizontal band of rows)
+    y_lo = (H * rank) // world
+    y_hi = (H * (rank + 1)) // world
+    rect = (0, y_lo, W, y_hi - y_lo)
+    accum = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
+    aux = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for p in range(args.warmup):
+        RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity)
+    barrier()
+    t0 = time.perf_counter()
+    tot = {}
+    for p in range(args.warmup, args.warmup + args.steps):
+        c = RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity)
+        for k, v in c.items():
+            tot[k] = tot.get(k, 0) + v
+    if world > 1:
+        # framebuffer gather over xGMI: every rank ends up with the whole frame (slabs are contiguous rows)
+        for buf in (accum, aux):
+            rows = [buf.view(H, W * 4)[(H * r) // world:(H * (r + 1)) // world] for r in range(world)]
+            if len({t.shape[0] for t in rows}) == 1:
+                dist.all_gather_into_tensor(buf.view(H, W * 4), rows[rank].contiguous())
+            else:
+                for r in range(world):
+                    dist.broadcast(rows[r], src=r)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    keys = ["rays_processed", "shadows_cast", "nodes", "packets", "shadow_nodes", "shadow_packets", "hits",
+            "trace_launches", "shadow_launches", "shade_launches"]
+    vals = torch.tensor([float(tot[k]) for k in keys] + [tot["trace_ms"], tot["shadow_ms"], tot["shade_ms"], dt],
+                        dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = vals.clone()
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dt = float(mx[-1])
+    agg = {k: float(vals[i]) for i, k in enumerate(keys)}
+    trace_ms, shadow_ms, shade_ms = (float(vals[len(keys) + i]) for i in range(3))
+
+    if rank == 0:
+        rays = agg["rays_processed"]
+        value = rays / dt / 1e6
+        # roofline of the dominant kernel (closest-hit traversal), algorithmic bytes over its own HIP-event time
+        alg_bytes = NODE_B * agg["nodes"] + PACKET_B * agg["packets"] + (RAY_B + HIT_B) * rays
+        launches = max(1.0, agg["trace_launches"])
+        achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (primary + diffuse bounce) at 1080p",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"procedural Sponza-class atrium, {args.tris} tris, {W}x{H}, 1 spp per step, max_generations 8, "
+                            f"monte_carlo_max 32 (BASELINE.json configs[1])",
+                "parallelism": f"tile slabs x{world}, scene replicated",
+                "rays_per_step": rays / args.steps,
+                "shadow_rays_per_step": agg["shadows_cast"] / args.steps,
+                "ray_capacity": args.ray_capacity,
+                "scene_package_s": t_pack,
+            },
+            "roofline": {
+                "kernel": "k_trace<0> (closest-hit traversal)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launches": int(launches),
+                "avg_launch_ms": trace_ms / launches,
+                "algorithmic_bytes_per_launch": alg_bytes / launches,
+                "bytes_per_ray": alg_bytes / max(1.0, rays),
+                "kernel_ms": {"trace": trace_ms, "shadow": shadow_ms, "shade": shade_ms, "wall": dt * 1e3},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            cw, ch = (int(v) for v in args.cpu_sample.split("x"))
+            out["cpu_baseline"] = cpu_baseline(desc, cam, (cw, ch), args.seed, threads)
+        print(json.dumps(out), flush=True)
+    RE.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

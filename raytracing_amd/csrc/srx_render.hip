@@ -38,6 +38,7 @@ struct srx_renderer {
     DeviceCounts* h_counts = nullptr; // pinned
     bool timing = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool shadow_timing_pending = false;
     // per-call accumulators
     uint64_t top = 0;
     srx_counters acc;
@@ -99,6 +100,15 @@ int ensure_sample_buffer(srx_renderer* r, uint64_t pixels) {
     return 0;
 }
 
+int collect_shadow_timing(srx_renderer* r) {
+    if (!r->shadow_timing_pending) return 0;
+    float ms = 0;
+    SRX_HIP(hipEventElapsedTime(&ms, r->ev[4], r->ev[5]));
+    r->acc.shadow_ms += ms;
+    r->shadow_timing_pending = false;
+    return 0;
+}
+
 // Process the queue segment [begin, end) of generation `gen`; children go above r->top.
 int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
     const GScene& g = r->scene->g;
@@ -142,6 +152,7 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         if (r->timing) SRX_HIP(hipEventRecord(r->ev[3], r->stream));
         SRX_HIP(hipMemcpyAsync(r->h_counts, r->d_counts, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
         SRX_HIP(hipStreamSynchronize(r->stream));
+        if (collect_shadow_timing(r)) return 1;
         const uint64_t n_children = r->h_counts->out_count, n_shadow = r->h_counts->shadow_count;
         if (n_children > n * fan || r->top + n_children > r->capacity) SRX_FAIL("srx: internal error, child count exceeds the reserved slots");
         if (n_shadow > r->shadow_capacity) SRX_FAIL("srx: internal error, shadow count exceeds the queue");
@@ -164,7 +175,7 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         if (n_shadow) r->acc.shadow_launches++;
         if (r->timing) {
             float ms = 0;
-            if (n_shadow) { SRX_HIP(hipEventSynchronize(r->ev[5])); SRX_HIP(hipEventElapsedTime(&ms, r->ev[4], r->ev[5])); r->acc.shadow_ms += ms; }
+            if (n_shadow) r->shadow_timing_pending = true;   // read at the next sync point (same stream => complete by then)
             SRX_HIP(hipEventElapsedTime(&ms, r->ev[0], r->ev[1])); r->acc.trace_ms += ms;
             SRX_HIP(hipEventElapsedTime(&ms, r->ev[2], r->ev[3])); r->acc.shade_ms += ms;
         }
@@ -182,6 +193,7 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
 
 int begin_call(srx_renderer* r) {
     std::memset(&r->acc, 0, sizeof(r->acc));
+    r->shadow_timing_pending = false;
     SRX_HIP(hipMemsetAsync(r->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), r->stream));
     return 0;
 }
@@ -190,6 +202,7 @@ int end_call(srx_renderer* r, srx_counters* out) {
     unsigned long long c[CTR_COUNT];
     SRX_HIP(hipMemcpyAsync(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost, r->stream));
     SRX_HIP(hipStreamSynchronize(r->stream));
+    if (collect_shadow_timing(r)) return 1;
     r->acc.nodes = c[CTR_NODES]; r->acc.packets = c[CTR_PACKETS];
     r->acc.shadow_nodes = c[CTR_SNODES]; r->acc.shadow_packets = c[CTR_SPACKETS];
     r->acc.hits = c[CTR_HITS]; r->acc.texels = c[CTR_TEXELS]; r->acc.pdf_lookups = c[CTR_PDF];
