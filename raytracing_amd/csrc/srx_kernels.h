@@ -11,7 +11,9 @@ struct TraceArgs {
     uint8_t* lit;                          // shadow form, API
     const GShadow* shadow_q;               // shadow form, renderer queue
     float* sample3;                        // shadow form, renderer: per-pixel sample sums (atomic)
-    unsigned long long* counters;          // [0] node tests, [1] packet tests
+    unsigned long long* counters;          // [0] node tests, [1] packet tests (of slot 0)
+    uint32_t counter_slot_mask;            // counters are replicated in (mask+1) slots to spread the atomics ...
+    uint32_t counter_slot_stride;          // ... slot s starts at counters + s*stride (u64 units); host sums the slots
 };
 
 // mode 0: closest hit; 1: shadow (API form, writes lit[]); 2: shadow (renderer queue form, adds lit contributions)
@@ -34,7 +36,8 @@ struct ShadeArgs {
     GShadow* shadow_q;             // shadow rays of this segment (one per hit and sun light)
     uint32_t* shadow_count;
     float* sample3;                // per-pixel sample sums (float atomics)
-    unsigned long long* counters;  // [4] hits, [5] texels, [6] pdf lookups, [7] children
+    unsigned long long* counters;  // [4] hits, [5] texels, [6] pdf lookups, [7] children (of slot 0)
+    uint32_t counter_slot_mask, counter_slot_stride;   // as in TraceArgs
 };
 
 extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hipStream_t stream);

@@ -17,7 +17,7 @@
 namespace {
 
 enum { CTR_NODES = 0, CTR_PACKETS = 1, CTR_SNODES = 2, CTR_SPACKETS = 3, CTR_HITS = 4, CTR_TEXELS = 5, CTR_PDF = 6,
-       CTR_CHILDREN = 7, CTR_COUNT = 8 };
+       CTR_CHILDREN = 7, CTR_COUNT = 8, CTR_SLOTS = 256 };
 
 struct DeviceCounts { uint32_t out_count, shadow_count; };
 
@@ -60,7 +60,7 @@ extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_
     chk(hipMalloc((void**)&r->hits, ray_capacity * sizeof(GHit)));
     chk(hipMalloc((void**)&r->shadow_q, r->shadow_capacity * sizeof(GShadow)));
     chk(hipMalloc((void**)&r->d_counts, sizeof(DeviceCounts)));
-    chk(hipMalloc((void**)&r->d_counters, CTR_COUNT * sizeof(unsigned long long)));
+    chk(hipMalloc((void**)&r->d_counters, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long)));
     chk(hipHostMalloc((void**)&r->h_counts, sizeof(DeviceCounts)));
     for (int i = 0; i < 6; i++) chk(hipEventCreate(&r->ev[i]));
     if (e != hipSuccess) {
@@ -134,7 +134,7 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         t.dir = &r->rays[begin].dx; t.dir_stride = sizeof(GRay) / 4;
         t.n = (uint32_t)n;
         t.hits = r->hits;
-        t.counters = r->d_counters + CTR_NODES;
+        t.counters = r->d_counters + CTR_NODES; t.counter_slot_mask = CTR_SLOTS - 1; t.counter_slot_stride = CTR_COUNT;
         if (r->timing) SRX_HIP(hipEventRecord(r->ev[0], r->stream));
         SRX_HIP(srx_launch_trace(0, g, t, r->stream));
         if (r->timing) SRX_HIP(hipEventRecord(r->ev[1], r->stream));
@@ -146,7 +146,7 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         s.rays = r->rays + begin; s.hits = r->hits; s.n = (uint32_t)n; s.generation = gen;
         s.out_rays = r->rays + r->top; s.out_count = &r->d_counts->out_count;
         s.shadow_q = r->shadow_q; s.shadow_count = &r->d_counts->shadow_count;
-        s.sample3 = r->sample3; s.counters = r->d_counters;
+        s.sample3 = r->sample3; s.counters = r->d_counters; s.counter_slot_mask = CTR_SLOTS - 1; s.counter_slot_stride = CTR_COUNT;
         if (r->timing) SRX_HIP(hipEventRecord(r->ev[2], r->stream));
         SRX_HIP(srx_launch_shade(g, s, r->stream));
         if (r->timing) SRX_HIP(hipEventRecord(r->ev[3], r->stream));
@@ -164,7 +164,7 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
             sh.org = &r->shadow_q[0].ox; sh.org_stride = sizeof(GShadow) / 4;
             sh.n = (uint32_t)n_shadow;
             sh.shadow_q = r->shadow_q; sh.sample3 = r->sample3;
-            sh.counters = r->d_counters + CTR_SNODES;
+            sh.counters = r->d_counters + CTR_SNODES; sh.counter_slot_mask = CTR_SLOTS - 1; sh.counter_slot_stride = CTR_COUNT;
             if (r->timing) SRX_HIP(hipEventRecord(r->ev[4], r->stream));
             SRX_HIP(srx_launch_trace(2, g, sh, r->stream));
             if (r->timing) SRX_HIP(hipEventRecord(r->ev[5], r->stream));
@@ -194,14 +194,17 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
 int begin_call(srx_renderer* r) {
     std::memset(&r->acc, 0, sizeof(r->acc));
     r->shadow_timing_pending = false;
-    SRX_HIP(hipMemsetAsync(r->d_counters, 0, CTR_COUNT * sizeof(unsigned long long), r->stream));
+    SRX_HIP(hipMemsetAsync(r->d_counters, 0, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long), r->stream));
     return 0;
 }
 
 int end_call(srx_renderer* r, srx_counters* out) {
-    unsigned long long c[CTR_COUNT];
-    SRX_HIP(hipMemcpyAsync(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost, r->stream));
+    static thread_local std::vector<unsigned long long> all;
+    all.resize((size_t)CTR_SLOTS * CTR_COUNT);
+    SRX_HIP(hipMemcpyAsync(all.data(), r->d_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
     SRX_HIP(hipStreamSynchronize(r->stream));
+    unsigned long long c[CTR_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sl = 0; sl < CTR_SLOTS; sl++) for (int k = 0; k < CTR_COUNT; k++) c[k] += all[(size_t)sl * CTR_COUNT + k];
     if (collect_shadow_timing(r)) return 1;
     r->acc.nodes = c[CTR_NODES]; r->acc.packets = c[CTR_PACKETS];
     r->acc.shadow_nodes = c[CTR_SNODES]; r->acc.shadow_packets = c[CTR_SPACKETS];

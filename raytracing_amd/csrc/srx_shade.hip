@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool live = idx < a.n;
+    __shared__ GRay s_stage[4][128];          // per-wave staging of surviving children (24 KB)
+    __shared__ uint32_t s_wave_count[4];
+    __shared__ uint32_t s_base[2];
+    GRay* const stage = s_stage[threadIdx.x >> 6];
+    uint32_t staged = 0;                      // wave-uniform
 
     GRay ray;
     GHit hit;
@@ -222,30 +227,33 @@ __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
         m.config(flipped_output, normal, n1_ior, m.IOR);               // Core.h:454
     }
 
-    // ---- direct light: one shadow ray per sun (Core.h:457-471), appended with one atomic per wave
+    // ---- direct light: one shadow ray per sun (Core.h:457-471). One reservation per BLOCK: a returning atomic
+    // on one hot word per wave would serialise the chip (~88 of them per microsecond, chip-wide).
+    const int wave = threadIdx.x >> 6;
+    const unsigned long long hit_bal = __ballot(is_hit);
+    if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(hit_bal);
+    __syncthreads();
+    uint32_t hit_rank = (uint32_t)__popcll(hit_bal & lt_mask), block_hits = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; wv++) {
+        const uint32_t c = s_wave_count[wv];
+        if (wv < wave) hit_rank += c;
+        block_hits += c;
+    }
+    if (threadIdx.x == 0 && sc.n_suns && block_hits) s_base[0] = atomicAdd(a.shadow_count, block_hits * sc.n_suns);
+    __syncthreads();
     for (uint32_t s = 0; s < sc.n_suns; s++) {
-        f3 contrib;
-        f3 pos;
         if (is_hit) {
-            pos = position + 0.001f * geo_normal;
+            const f3 pos = position + 0.001f * geo_normal;
             const f3 ldir(sc.suns[s].dir[0], sc.suns[s].dir[1], sc.suns[s].dir[2]);
             m.set_input(ldir, sc.arccos_lookup);
             const f3 rc = m.fast_BRDF_co();
-            contrib = thr * (rc * f3(sc.suns[s].emission[0], sc.suns[s].emission[1], sc.suns[s].emission[2]));
-        }
-        const unsigned long long em = __ballot(is_hit);
-        if (em) {
-            const int first = __ffsll((long long)em) - 1;
-            uint32_t base = 0;
-            if (lane == first) base = atomicAdd(a.shadow_count, (uint32_t)__popcll(em));
-            base = (uint32_t)__shfl((int)base, first, 64);
-            if (is_hit) {
-                GShadow q;
-                q.ox = pos.x; q.oy = pos.y; q.oz = pos.z;
-                q.pixel_sun = (ray.pixel & 0x00FFFFFFu) | (s << 24);
-                q.cr = contrib.x; q.cg = contrib.y; q.cb = contrib.z; q.pad = 0.0f;
-                a.shadow_q[base + (uint32_t)__popcll(em & lt_mask)] = q;
-            }
+            const f3 contrib = thr * (rc * f3(sc.suns[s].emission[0], sc.suns[s].emission[1], sc.suns[s].emission[2]));
+            GShadow q;
+            q.ox = pos.x; q.oy = pos.y; q.oz = pos.z;
+            q.pixel_sun = (ray.pixel & 0x00FFFFFFu) | (s << 24);
+            q.cr = contrib.x; q.cg = contrib.y; q.cb = contrib.z; q.pad = 0.0f;
+            a.shadow_q[s_base[0] + hit_rank * sc.n_suns + s] = q;
         }
     }
 
@@ -340,16 +348,41 @@ __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
                 if (i >= bounce_count) active = false;
             }
         }
+        // compaction: survivors are staged in this wave's LDS buffer (ballot + prefix count give the slot);
+        // the buffer is flushed to the queue with ONE reservation whenever it holds more than 64 rays
         const unsigned long long em = __ballot(emit);
         if (em) {
-            const int first = __ffsll((long long)em) - 1;
-            uint32_t base = 0;
-            if (lane == first) base = atomicAdd(a.out_count, (uint32_t)__popcll(em));
-            base = (uint32_t)__shfl((int)base, first, 64);
             if (emit) {
-                a.out_rays[base + (uint32_t)__popcll(em & lt_mask)] = child;
+                stage[staged + (uint32_t)__popcll(em & lt_mask)] = child;
                 n_children++;
             }
+            staged += (uint32_t)__popcll(em);
+            if (staged > 64u) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.out_count, staged);
+                base = (uint32_t)__shfl((int)base, 0, 64);
+                for (uint32_t k = lane; k < staged; k += 64) a.out_rays[base + k] = stage[k];
+                staged = 0;
+            }
+        }
+    }
+    // what is left is flushed with one reservation per block
+    __syncthreads();
+    if (lane == 0) s_wave_count[wave] = staged;
+    __syncthreads();
+    {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int wv = 0; wv < 4; wv++) {
+            const uint32_t c = s_wave_count[wv];
+            if (wv < wave) before += c;
+            total += c;
+        }
+        if (threadIdx.x == 0 && total) s_base[1] = atomicAdd(a.out_count, total);
+        __syncthreads();
+        if (total) {
+            const uint32_t base = s_base[1] + before;
+            for (uint32_t k = lane; k < staged; k += 64) a.out_rays[base + k] = stage[k];
         }
     }
 
@@ -357,10 +390,11 @@ __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
     const uint32_t w_hits = (uint32_t)__popcll(__ballot(is_hit));
     const uint32_t w_tex = wave_sum_u32(n_texels), w_pdf = wave_sum_u32(n_pdf), w_child = wave_sum_u32(n_children);
     if (lane == 0 && a.counters) {
-        if (w_hits) atomicAdd(&a.counters[4], (unsigned long long)w_hits);
-        if (w_tex) atomicAdd(&a.counters[5], (unsigned long long)w_tex);
-        if (w_pdf) atomicAdd(&a.counters[6], (unsigned long long)w_pdf);
-        if (w_child) atomicAdd(&a.counters[7], (unsigned long long)w_child);
+        unsigned long long* c = a.counters + (size_t)(blockIdx.x & a.counter_slot_mask) * a.counter_slot_stride;
+        if (w_hits) atomicAdd(&c[4], (unsigned long long)w_hits);
+        if (w_tex) atomicAdd(&c[5], (unsigned long long)w_tex);
+        if (w_pdf) atomicAdd(&c[6], (unsigned long long)w_pdf);
+        if (w_child) atomicAdd(&c[7], (unsigned long long)w_child);
     }
 }
 

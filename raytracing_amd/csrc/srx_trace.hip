@@ -166,9 +166,19 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         } else if (MODE == 1) {
             a.lit[ray] = best_t > 9999.0f ? 1 : 0;   // SunLight::intersects (Primitives.h:44-50)
         }
-        if (a.counters) {
-            atomicAdd(&a.counters[0], (unsigned long long)n_nodes);
-            atomicAdd(&a.counters[1], (unsigned long long)n_packets);
+    }
+    if (a.counters) {
+        // one atomic per wave and counter, spread over replicated slots (a single hot word serialises the chip)
+        uint32_t wn = (live && sub == 0) ? n_nodes : 0u, wp = (live && sub == 0) ? n_packets : 0u;
+#pragma unroll
+        for (int off = 32; off >= 8; off >>= 1) {
+            wn += (uint32_t)__shfl_xor((int)wn, off, 64);
+            wp += (uint32_t)__shfl_xor((int)wp, off, 64);
+        }
+        if (lane == 0) {
+            unsigned long long* c = a.counters + (size_t)(blockIdx.x & a.counter_slot_mask) * a.counter_slot_stride;
+            atomicAdd(&c[0], (unsigned long long)wn);
+            atomicAdd(&c[1], (unsigned long long)wp);
         }
     }
     if (MODE == 2 && live && sub < 3 && best_t > 9999.0f) {
