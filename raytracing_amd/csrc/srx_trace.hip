@@ -18,23 +18,70 @@
 #define SRX_OCTETS_PER_BLOCK (SRX_TRACE_THREADS / 8)
 
 
+// ---- cross-lane helpers inside an octet, all DPP (no LDS crossbar): quad_perm for lane^1, ^2, ^3 and
+// row_half_mirror (lane -> 7-lane inside each 8-lane half row) for the other quad.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+#define DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define DPP_XOR3 0x1B          // quad_perm [3,2,1,0]
+#define DPP_HALF_MIRROR 0x141  // row_half_mirror
+
 __device__ __forceinline__ uint32_t octet_min_u32(uint32_t v) {
-    v = min(v, (uint32_t)__shfl_xor((int)v, 1, 8));
-    v = min(v, (uint32_t)__shfl_xor((int)v, 2, 8));
-    v = min(v, (uint32_t)__shfl_xor((int)v, 4, 8));
+    v = min(v, dpp_u32<DPP_XOR1>(v));
+    v = min(v, dpp_u32<DPP_XOR2>(v));
+    v = min(v, dpp_u32<DPP_HALF_MIRROR>(v));
     return v;
+}
+// number of the 7 other lanes of the octet whose key is smaller than this lane's
+__device__ __forceinline__ int octet_rank_u32(uint32_t ord) {
+    const uint32_t h = dpp_u32<DPP_HALF_MIRROR>(ord);
+    int rank = (dpp_u32<DPP_XOR1>(ord) < ord) + (dpp_u32<DPP_XOR2>(ord) < ord) + (dpp_u32<DPP_XOR3>(ord) < ord);
+    rank += (h < ord) + (dpp_u32<DPP_XOR1>(h) < ord) + (dpp_u32<DPP_XOR2>(h) < ord) + (dpp_u32<DPP_XOR3>(h) < ord);
+    return rank;
+}
+
+// x86 vminps/vmaxps return the SECOND operand when either is NaN. FAST (no NaN can occur: every ray of the wave
+// has finite 1/d and -o/d, so the slab FMAs give finite or infinite values only) uses the hardware min/max
+// (v_min3/v_max3), which agree except for the sign of a zero result; a zero result is "no hit" either way.
+template <bool FAST> __device__ __forceinline__ float x86_min(float a, float b) { return FAST ? __builtin_fminf(a, b) : (a < b ? a : b); }
+template <bool FAST> __device__ __forceinline__ float x86_max(float a, float b) { return FAST ? __builtin_fmaxf(a, b) : (a > b ? a : b); }
+
+// One child box per lane (BVH.h:940-988) + ordering key (Core.h:74-78). Returns the raw result bits (tmin or 0).
+template <bool FAST>
+__device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, const f3 inv, const f3 fused) {
+    const float tx1 = __fmaf_rn(A.x, inv.x, fused.x), tx2 = __fmaf_rn(A.w, inv.x, fused.x);
+    const float ty1 = __fmaf_rn(A.y, inv.y, fused.y), ty2 = __fmaf_rn(B.x, inv.y, fused.y);
+    const float tz1 = __fmaf_rn(A.z, inv.z, fused.z), tz2 = __fmaf_rn(B.y, inv.z, fused.z);
+    const float tminx = x86_min<FAST>(tx1, tx2), tminy = x86_min<FAST>(ty1, ty2), tminz = x86_min<FAST>(tz1, tz2);
+    const float tmaxx = x86_max<FAST>(tx1, tx2), tmaxy = x86_max<FAST>(ty1, ty2), tmaxz = x86_max<FAST>(tz1, tz2);
+    const float tmin = x86_max<FAST>(tminz, x86_max<FAST>(tminy, tminx));
+    const float tmax = x86_min<FAST>(tmaxz, x86_min<FAST>(tmaxy, tmaxx));
+    const bool hit = (tmax >= 0.0f) && (tmin < tmax);
+    return hit ? f2u(tmin) : 0u;
 }
 
 // MODE 0: closest hit.  MODE 1: shadow, API form (writes lit[]).  MODE 2: shadow, renderer queue form.
 template <int MODE>
 __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArgs a) {
-    extern __shared__ uint2 s_stack[];   // [depth][SRX_OCTETS_PER_BLOCK]
+    // LDS: traversal stack [depth][32 octets] of (tmin bits << 32 | link), then one 16-B best-hit record per octet
+    extern __shared__ unsigned long long s_mem[];
+    unsigned long long* const s_stack = s_mem;
+    uint4* const s_best = (uint4*)(s_mem + (size_t)sc.stack_depth * SRX_OCTETS_PER_BLOCK);
     const int sub = threadIdx.x & 7;
     const int oct = threadIdx.x >> 3;
     const int lane = threadIdx.x & 63;
     const int oct_shift = lane & ~7;
-    const uint32_t ray = blockIdx.x * SRX_OCTETS_PER_BLOCK + oct;
-    const bool live = ray < a.n;
+    // XCD-aware block -> ray-range map: blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), so
+    // XCD x works on the x-th contiguous eighth of the queue (queue order follows pixel / parent order).
+    // Speed only; any placement gives the same results.
+    const uint32_t nblk = gridDim.x;
+    const uint32_t per_xcd = (nblk + 7u) >> 3;
+    const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t ray = lblock * SRX_OCTETS_PER_BLOCK + oct;
+    const bool live = (lblock < nblk) && (ray < a.n);
 
     f3 o, d;
     uint32_t pixel_sun = 0;
@@ -53,95 +100,89 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     // Core.h:53-54: fused = (-1*o)/d, inv = 1/d (IEEE divides, zeros unguarded)
     const f3 fused = (o * -1.0f) / d;
     const f3 inv = f3(1.0f) / d;
+    const bool finite6 = well_defined(fused.x) && well_defined(fused.y) && well_defined(fused.z) &&
+                         well_defined(inv.x) && well_defined(inv.y) && well_defined(inv.z);
+    const bool fast = !__any(live && !finite6);   // wave-uniform
 
     float best_t = SRX_MISS_DISTANCE;
-    float best_u = -1.0f, best_v = -1.0f;
-    uint32_t best_mat = 0xFFFFFFFFu;
-    int best_tri = 0;
     uint32_t n_nodes = 0, n_packets = 0;
 
     int sp = live ? 0 : -1;
-    if (sub == 0) s_stack[oct] = make_uint2(0u, 0u);   // root: node 0, distance 0, no packets (Core.h:59-61)
+    if (sub == 0) s_stack[oct] = 0ull;   // root: node 0, distance 0, no packets (Core.h:59-61)
     __builtin_amdgcn_wave_barrier();
 
     while (__any(sp >= 0)) {
-        if (sp >= 0) {
-            const uint2 e = s_stack[sp * SRX_OCTETS_PER_BLOCK + oct];
+        // pop until an entry survives the distance cull (Core.h:63-68)
+        uint32_t link = 0;
+        bool go = false;
+        while (sp >= 0) {
+            const unsigned long long e = s_stack[sp * SRX_OCTETS_PER_BLOCK + oct];
             sp--;
-            const float dist = u2f(e.y);
-            if (!(dist >= best_t)) {                                   // Core.h:65-68
-                const uint32_t cnt = e.x >> SRX_LINK_COUNT_SHIFT;
-                const uint32_t idx = e.x & SRX_LINK_INDEX_MASK;
-                if (cnt == 0) {
-                    // ---- inner node: one child box per lane (BVH.h:940-988)
-                    const GNode* nd = sc.nodes + idx;
-                    const float4 A = nd->a[sub];
-                    const float4 B = nd->b[sub];
-                    n_nodes++;
-                    const float tx1 = __fmaf_rn(A.x, inv.x, fused.x), tx2 = __fmaf_rn(A.w, inv.x, fused.x);
-                    const float ty1 = __fmaf_rn(A.y, inv.y, fused.y), ty2 = __fmaf_rn(B.x, inv.y, fused.y);
-                    const float tz1 = __fmaf_rn(A.z, inv.z, fused.z), tz2 = __fmaf_rn(B.y, inv.z, fused.z);
-                    const float tminx = mm_min(tx1, tx2), tminy = mm_min(ty1, ty2), tminz = mm_min(tz1, tz2);
-                    const float tmaxx = mm_max(tx1, tx2), tmaxy = mm_max(ty1, ty2), tmaxz = mm_max(tz1, tz2);
-                    const float tmin = mm_max(tminz, mm_max(tminy, tminx));
-                    const float tmax = mm_min(tmaxz, mm_min(tmaxy, tmaxx));
-                    const bool hit = (tmax >= 0.0f) && (tmin < tmax);
-                    const uint32_t rb = hit ? f2u(tmin) : 0u;
-                    // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id; result==0 (either sign) is "no hit";
-                    // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86)
-                    const bool allow = (rb & 0x7fffffffu) != 0u;
-                    const uint32_t kb = allow ? ((rb & ~7u) | (uint32_t)sub) : 0u;
-                    const bool valid = (kb & 0x7fffffffu) != 0u;
-                    // total order of floats as unsigned ints (no NaN keys exist)
-                    const uint32_t ord = valid ? ((kb & 0x80000000u) ? ~kb : (kb | 0x80000000u)) : 0xFFFFFFFFu;
-                    int rank = 0;
-#pragma unroll
-                    for (int m = 1; m < 8; m++) {
-                        const uint32_t other = (uint32_t)__shfl_xor((int)ord, m, 8);
-                        rank += (other < ord) ? 1 : 0;
-                    }
-                    const unsigned long long bal = __ballot(valid);
-                    const int nvalid = __popc((uint32_t)(bal >> oct_shift) & 0xFFu);
-                    // push far -> near so the nearest child is popped first (Core.h:98-106); stored distance is the
-                    // unmodified tmin
-                    if (valid) s_stack[(sp + nvalid - rank) * SRX_OCTETS_PER_BLOCK + oct] = make_uint2(f2u(B.z), rb);
-                    sp += nvalid;
-                } else {
-                    // ---- leaf: cnt packets of 8 triangles, one triangle per lane (Primitives.h:159-202)
-                    for (uint32_t k = 0; k < cnt; k++) {
-                        const GPacket* pk = sc.packets + idx + k;
-                        const float4 A = pk->a[sub];
-                        const float4 B = pk->b[sub];
-                        const float4 C = pk->c[sub];
-                        n_packets++;
-                        const float e1x = A.w, e1y = B.x, e1z = B.y;
-                        const float e2x = B.z, e2y = B.w, e2z = C.x;
-                        // pvec = cross_avx(slope, p1p3) (VecLib.cpp:282-289)
-                        const float c1 = d.z * e2y, c2 = d.x * e2z, c3 = d.y * e2x;
-                        const float px = __fmaf_rn(d.y, e2z, -c1), py = __fmaf_rn(d.z, e2x, -c2), pz = __fmaf_rn(d.x, e2y, -c3);
-                        const float det = __fmaf_rn(e1z, pz, __fmaf_rn(e1y, py, e1x * px));      // dot_avx :290-303
-                        const float invDet = 1.0f / det;
-                        const float tx = o.x - A.x, ty = o.y - A.y, tz = o.z - A.z;
-                        const float q1 = tz * e1y, q2 = tx * e1z, q3 = ty * e1x;
-                        const float qx = __fmaf_rn(ty, e1z, -q1), qy = __fmaf_rn(tz, e1x, -q2), qz = __fmaf_rn(tx, e1y, -q3);
-                        const float uu = invDet * __fmaf_rn(tz, pz, __fmaf_rn(ty, py, tx * px));  // dot_mul_avx :309-325
-                        const float vv = invDet * __fmaf_rn(d.z, qz, __fmaf_rn(d.y, qy, d.x * qx));
-                        const float tt = invDet * __fmaf_rn(e2z, qz, __fmaf_rn(e2y, qy, e2x * qx));
-                        const bool pass = (uu >= 0.0f) && (vv >= 0.0f) && ((uu + vv) <= 1.0f);
-                        // closest-hit select (Core.h:231-239): lanes in order, strict '<' => lowest lane wins ties
-                        const bool cand = pass && (tt > 0.0f) && (tt < best_t);
-                        if (__ballot(cand) == 0ull) continue;
-                        const uint32_t tb = cand ? f2u(tt) : 0xFFFFFFFFu;
-                        const uint32_t m = octet_min_u32(tb);
-                        if (m != 0xFFFFFFFFu) {
+            if (!(u2f((uint32_t)(e >> 32)) >= best_t)) { link = (uint32_t)e; go = true; break; }
+        }
+        if (go) {
+            const uint32_t cnt = link >> SRX_LINK_COUNT_SHIFT;
+            const uint32_t idx = link & SRX_LINK_INDEX_MASK;
+            const bool leaf = cnt != 0;
+            // node (2 lines) and packet (3 lines) fetches are issued together, before the two kinds part ways
+            const char* base = leaf ? (const char*)(sc.packets + idx) : (const char*)(sc.nodes + idx);
+            const float4 A = *(const float4*)(base + 16 * sub);
+            const float4 B = *(const float4*)(base + 128 + 16 * sub);
+            if (!leaf) {
+                n_nodes++;
+                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused) : node_test<false>(A, B, inv, fused);
+                // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id; result==0 (either sign) is "no hit";
+                // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86)
+                const bool allow = (rb & 0x7fffffffu) != 0u;
+                const uint32_t kb = allow ? ((rb & ~7u) | (uint32_t)sub) : 0u;
+                const bool valid = (kb & 0x7fffffffu) != 0u;
+                // total order of floats as unsigned ints (no NaN keys exist); invalid lanes sort last
+                const uint32_t ord = valid ? ((kb & 0x80000000u) ? ~kb : (kb | 0x80000000u)) : 0xFFFFFFFFu;
+                const int rank = octet_rank_u32(ord);
+                const unsigned long long bal = __ballot(valid);
+                const int nvalid = __popc((uint32_t)(bal >> oct_shift) & 0xFFu);
+                // push far -> near so the nearest child is popped first (Core.h:98-106); stored distance is the
+                // unmodified tmin
+                if (valid) s_stack[(sp + nvalid - rank) * SRX_OCTETS_PER_BLOCK + oct] = ((unsigned long long)rb << 32) | f2u(B.z);
+                sp += nvalid;
+            } else {
+                // ---- leaf: one packet of 8 triangles per trip, one triangle per lane (Primitives.h:159-202).
+                // The rest of a multi-packet leaf goes back on top with distance -inf: it is never culled, exactly
+                // like the reference's inner `for` over the leaf's packets (Core.h:179).
+                const float4 C = *(const float4*)(base + 256 + 16 * sub);
+                if (cnt > 1) {
+                    sp++;
+                    if (sub == 0) s_stack[sp * SRX_OCTETS_PER_BLOCK + oct] = (0xFF800000ull << 32) | (((cnt - 1) << SRX_LINK_COUNT_SHIFT) | (idx + 1));
+                }
+                n_packets++;
+                const float e1x = A.w, e1y = B.x, e1z = B.y;
+                const float e2x = B.z, e2y = B.w, e2z = C.x;
+                // pvec = cross_avx(slope, p1p3) (VecLib.cpp:282-289)
+                const float c1 = d.z * e2y, c2 = d.x * e2z, c3 = d.y * e2x;
+                const float px = __fmaf_rn(d.y, e2z, -c1), py = __fmaf_rn(d.z, e2x, -c2), pz = __fmaf_rn(d.x, e2y, -c3);
+                const float det = __fmaf_rn(e1z, pz, __fmaf_rn(e1y, py, e1x * px));      // dot_avx :290-303
+                const float invDet = 1.0f / det;
+                const float tx = o.x - A.x, ty = o.y - A.y, tz = o.z - A.z;
+                const float q1 = tz * e1y, q2 = tx * e1z, q3 = ty * e1x;
+                const float qx = __fmaf_rn(ty, e1z, -q1), qy = __fmaf_rn(tz, e1x, -q2), qz = __fmaf_rn(tx, e1y, -q3);
+                const float uu = invDet * __fmaf_rn(tz, pz, __fmaf_rn(ty, py, tx * px));  // dot_mul_avx :309-325
+                const float vv = invDet * __fmaf_rn(d.z, qz, __fmaf_rn(d.y, qy, d.x * qx));
+                const float tt = invDet * __fmaf_rn(e2z, qz, __fmaf_rn(e2y, qy, e2x * qx));
+                const bool pass = (uu >= 0.0f) && (vv >= 0.0f) && ((uu + vv) <= 1.0f);
+                // closest-hit select (Core.h:231-239): lanes in order, strict '<' => lowest lane wins ties
+                const bool cand = pass && (tt > 0.0f) && (tt < best_t);
+                if (__ballot(cand) != 0ull) {
+                    const uint32_t tb = cand ? f2u(tt) : 0xFFFFFFFFu;
+                    const uint32_t m = octet_min_u32(tb);
+                    if (m != 0xFFFFFFFFu) {
+                        best_t = u2f(m);
+                        if (MODE == 0) {
                             const unsigned long long wb = __ballot(tb == m);
                             const int w = __ffs((int)((uint32_t)(wb >> oct_shift) & 0xFFu)) - 1;
-                            best_t = u2f(m);
-                            best_u = __shfl(uu, w, 8);
-                            best_v = __shfl(vv, w, 8);
-                            best_mat = (uint32_t)__shfl((int)f2u(C.y), w, 8);
-                            best_tri = __shfl((int)f2u(C.z), w, 8);
-                            if (MODE != 0 && best_t <= 9999.0f) sp = -1;   // any occluder nearer than 9999 => shadowed
+                            // the winning lane records (u, v, material, tri_index) for its octet
+                            if (sub == w) s_best[oct] = make_uint4(f2u(uu), f2u(vv), f2u(C.y), f2u(C.z));
+                        } else if (best_t <= 9999.0f) {
+                            sp = -1;   // any occluder nearer than 9999 => shadowed (Primitives.h:44-50)
                         }
                     }
                 }
@@ -153,11 +194,12 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     if (live && sub == 0) {
         if (MODE == 0) {
             GHit h;
-            const bool hit = best_mat != 0xFFFFFFFFu;
-            h.material = best_mat;
+            const bool hit = best_t < SRX_MISS_DISTANCE;
+            const uint4 b = s_best[oct];
+            h.material = hit ? b.z : 0xFFFFFFFFu;
             h.t = hit ? best_t : -1.0f;
-            h.u = best_u; h.v = best_v;
-            h.tri_index = best_tri;
+            h.u = hit ? u2f(b.x) : -1.0f; h.v = hit ? u2f(b.y) : -1.0f;
+            h.tri_index = hit ? (int32_t)b.w : 0;
             a.hits[ray] = h;
             if (a.advanced_org3) {
                 const f3 p = o + (best_t * d) * 0.999f;
@@ -190,8 +232,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
 
 extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& a, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;
-    const uint32_t blocks = (a.n + SRX_OCTETS_PER_BLOCK - 1) / SRX_OCTETS_PER_BLOCK;
-    const size_t lds = (size_t)sc.stack_depth * SRX_OCTETS_PER_BLOCK * sizeof(uint2);
+    uint32_t blocks = (a.n + SRX_OCTETS_PER_BLOCK - 1) / SRX_OCTETS_PER_BLOCK;
+    blocks = (blocks + 7u) & ~7u;   // multiple of 8 so the XCD map covers every logical block exactly once
+    const size_t lds = (size_t)sc.stack_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4);
     if (mode == 0) hipLaunchKernelGGL(k_trace<0>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
     else if (mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
     else hipLaunchKernelGGL(k_trace<2>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
