@@ -99,9 +99,9 @@ def main():
     RE.load_scene(PS)
     RE.set_timing(True, ray_capacity=args.ray_capacity)
 
-    # tile slab of this rank (horizontal band of rows)
-    y_lo = (H * rank) // world
-    y_hi = (H * (rank + 1)) // world
+    # tile slab of this rank (horizontal band of tile rows)
+    from raytracing_amd import tiles
+    y_lo, y_hi = tiles.slab(rank, world, H)
     rect = (0, y_lo, W, y_hi - y_lo)
     accum = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
     aux = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
@@ -121,14 +121,11 @@ def main():
         for k, v in c.items():
             tot[k] = tot.get(k, 0) + v
     if world > 1:
-        # framebuffer gather over xGMI: every rank ends up with the whole frame (slabs are contiguous rows)
-        for buf in (accum, aux):
-            rows = [buf.view(H, W * 4)[(H * r) // world:(H * (r + 1)) // world] for r in range(world)]
-            if len({t.shape[0] for t in rows}) == 1:
-                dist.all_gather_into_tensor(buf.view(H, W * 4), rows[rank].contiguous())
-            else:
-                for r in range(world):
-                    dist.broadcast(rows[r], src=r)
+        # the two exchange steps: noise statistics all-reduce (KBs) and framebuffer all-gather over xGMI
+        sums, mins = tiles.slab_noise_stats(accum, aux, H, W, y_lo, y_hi)
+        tiles.allreduce_noise_stats(sums, mins)
+        tiles.gather_framebuffer(accum, H, W)
+        tiles.gather_framebuffer(aux, H, W)
     barrier()
     dt = time.perf_counter() - t0
 

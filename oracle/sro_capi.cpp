@@ -364,6 +364,16 @@ void sro_vec_ops(const float* a3, const float* b3, uint32_t n, float* reflect3, 
         dot1[i] = XYZ::dot(a, b);
     }
 }
+void sro_misc(const float* a3, const float* b3, float c, uint32_t n, float* fminus3, float* mix3, float* cdot1, float* slope3) {
+    for (uint32_t i = 0; i < n; i++) {
+        XYZ a(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]), b(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]);
+        XYZ f = float_minus_xyz(c, a), m = XYZ::linear_mix(c, a, b), s = XYZ::slope(a, b);
+        fminus3[3 * i] = f.X; fminus3[3 * i + 1] = f.Y; fminus3[3 * i + 2] = f.Z;
+        mix3[3 * i] = m.X; mix3[3 * i + 1] = m.Y; mix3[3 * i + 2] = m.Z;
+        cdot1[i] = XYZ::cdot(a, b);
+        slope3[3 * i] = s.X; slope3[3 * i + 1] = s.Y; slope3[3 * i + 2] = s.Z;
+    }
+}
 void sro_apply_rotation(const float* p3, const float* q4, uint32_t n, float* out3) {
     for (uint32_t i = 0; i < n; i++) {
         Quat q; q.X = q4[4 * i]; q.Y = q4[4 * i + 1]; q.Z = q4[4 * i + 2]; q.W = q4[4 * i + 3];

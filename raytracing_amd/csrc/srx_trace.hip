@@ -138,9 +138,12 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 const bool valid = (kb & 0x7fffffffu) != 0u;
                 // total order of floats as unsigned ints (no NaN keys exist); invalid lanes sort last
                 const uint32_t ord = valid ? ((kb & 0x80000000u) ? ~kb : (kb | 0x80000000u)) : 0xFFFFFFFFu;
-                const int rank = octet_rank_u32(ord);
                 const unsigned long long bal = __ballot(valid);
-                const int nvalid = __popc((uint32_t)(bal >> oct_shift) & 0xFFu);
+                const uint32_t vmask = (uint32_t)(bal >> oct_shift) & 0xFFu;
+                const int nvalid = __popc(vmask);
+                // Shadow casts only ask "is there a hit with 0 < t <= 9999": the answer does not depend on the visiting
+                // order (a box the reference culls is culled behind a hit it already has), so the sort is skipped.
+                const int rank = (MODE == 0) ? octet_rank_u32(ord) : __popc(vmask & ((1u << sub) - 1u));
                 // push far -> near so the nearest child is popped first (Core.h:98-106); stored distance is the
                 // unmodified tmin
                 if (valid) s_stack[(sp + nvalid - rank) * SRX_OCTETS_PER_BLOCK + oct] = ((unsigned long long)rb << 32) | f2u(B.z);

@@ -1,0 +1,82 @@
+"""CPU checks of the product's host side (no GPU, no compute kernels): packager parity with the oracle,
+table builder parity, C-ABI symbol coverage and error behaviour, tile sharding."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import sro
+from raytracing_amd import _lib, engine, scenes, tiles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "srx.h")).read()
+    declared = sorted(set(re.findall(r"\b(srx_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 19
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(_lib.EXPORTS) == declared
+
+
+@pytest.mark.parametrize("make", [
+    lambda: scenes.cornell(16, 1),
+    lambda: scenes.soup(3000, seed=4),
+    lambda: scenes.atrium(12000, res=(32, 18), subdiv=1, tex_size=16),
+    lambda: scenes.interior(5000, res=(32, 18), subdiv=1, tex_size=16),
+    lambda: scenes.diffuse_box(2000, res=(32, 18), subdiv=1),
+])
+def test_product_packager_matches_oracle_bytes(make):
+    desc = make()
+    PS = engine.package(desc)
+    S = sro.OracleScene(desc, build_tables=False)
+    n, pk, tr = S.packaged()
+    assert np.array_equal(n, PS.avx_bvh) and np.array_equal(pk, PS.avx_tri_data) and np.array_equal(tr, PS.tri_data)
+
+
+def test_degenerate_inputs():
+    """Ragged/edge inputs of the packager: one triangle, 9 coincident triangles (degenerate split, a leaf with
+    more than 8 triangles -> 2 packets), and zero triangles (the reference asserts, BVH.h:100)."""
+    one = scenes.soup(1, seed=1)
+    PS = engine.package(one)
+    assert PS.avx_bvh.shape[0] == 1 and PS.avx_tri_data.shape[0] == 1 and PS.tri_data.shape[0] == 1
+    nine = scenes.soup(1, seed=1)
+    nine.tris = np.repeat(nine.tris, 9)
+    PS = engine.package(nine)
+    S = sro.OracleScene(nine, build_tables=False)
+    n, pk, tr = S.packaged()
+    assert np.array_equal(n, PS.avx_bvh) and np.array_equal(pk, PS.avx_tri_data)
+    assert PS.avx_tri_data.shape[0] == 2 and PS.avx_bvh[0, 192:196].view(np.uint32)[0] == 2
+    empty = scenes.soup(1, seed=1)
+    empty.tris = empty.tris[:0]
+    with pytest.raises(_lib.SrxError):
+        engine.package(empty)
+
+
+def test_tables_match_oracle(tables):
+    a, p = engine.build_tables()
+    assert np.array_equal(a.view(np.uint32), tables[0].view(np.uint32))
+    assert np.array_equal(p.view(np.uint32), tables[1].view(np.uint32))
+
+
+def test_no_gpu_fails_loudly():
+    """Without a HIP device the library must refuse, not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.SrxError):
+        engine.RayEngine(0)
+
+
+def test_slabs_partition_the_frame():
+    for H in (1080, 2160, 37, 4):
+        for world in (1, 2, 3, 4, 8):
+            cuts = tiles.slabs(world, H)
+            assert cuts[0][0] == 0 and cuts[-1][1] == H
+            for (a0, a1), (b0, b1) in zip(cuts, cuts[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert all(y0 % tiles.TILE == 0 for y0, _ in cuts)
