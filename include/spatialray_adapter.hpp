@@ -1,0 +1,132 @@
+// include/spatialray_adapter.hpp — the reference's seam, re-expressed over the srx C-ABI (header only, C++17).
+//
+// A render loop written against the reference calls (Core.h:36-48, :346-359):
+//     RayEngine RE;  RE.load_scene(scene->package());
+//     CastResults r = RE.execute_ray_cast(position, slope);
+//     bool lit     = RE.execute_lighting_cast(position, light);
+//     XYZ radiance = RE.process_ray(stats, ray);
+// This header keeps those names and argument meanings. Single-ray calls go through the batched entry points
+// with n = 1 (correct, slow: a GPU wants batches); the *_batch members are what a ported loop should call.
+// Errors: the reference throws C++ exceptions; the C-ABI returns codes, the adapter rethrows std::runtime_error.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "srx.h"
+
+namespace spatialray {
+
+struct XYZ { float X = 0, Y = 0, Z = 0; };                       // XYZ.h:49-53
+struct XY { float X = 0, Y = 0; };
+
+struct CastResults {                                             // Coredefs.h:6-15
+    uint32_t material = 0xFFFFFFFFu;
+    float distance = 99999999999999999.f;
+    XYZ TUV{-1, -1, -1};
+    XY texUV{-1, -1};
+    int tri_index = 0;
+};
+struct Casting_Diagnostics { long long rays_processed = 0; long diffuses_cast = 0; long shadows_cast = 0; };   // Coredefs.h:17-23
+struct PackagedRay { XYZ position, slope; char generation = 0; XYZ coefficient{1, 1, 1}; uint64_t key = 0; };  // Ray.h:7-25
+struct SunLight { XYZ rotation, emission; };                     // Primitives.h:39-51
+
+inline void check(int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + srx_last_error());
+}
+
+// Scene::package() (Scene.h:90-179): owns the three flat arrays in the reference's layouts.
+class PackagedScene {
+public:
+    std::vector<srx_material> materials;
+    std::vector<srx_texture> textures;
+    std::vector<srx_sun> lights;
+    short max_generations = 10, monte_carlo_max = 32;            // Scene.h:27-30
+    float monte_carlo_modifier = 1.0f / 4;
+    explicit PackagedScene(const std::vector<srx_tri>& tris) {
+        check(srx_package_create(tris.data(), (uint32_t)tris.size(), &pkg_), "srx_package_create");
+    }
+    ~PackagedScene() { srx_package_destroy(pkg_); }
+    PackagedScene(const PackagedScene&) = delete;
+    PackagedScene& operator=(const PackagedScene&) = delete;
+    srx_scene_desc desc() const {
+        srx_scene_desc d;
+        std::memset(&d, 0, sizeof(d));
+        check(srx_package_get(pkg_, &d.nodes, &d.n_nodes, &d.packets, &d.n_packets, &d.tris, &d.n_tris), "srx_package_get");
+        d.materials = materials.data(); d.n_materials = (uint32_t)materials.size();
+        d.textures = textures.data(); d.n_textures = (uint32_t)textures.size();
+        d.suns = lights.data(); d.n_suns = (uint32_t)lights.size();
+        d.max_generations = max_generations; d.monte_carlo_max = monte_carlo_max; d.monte_carlo_modifier = monte_carlo_modifier;
+        return d;
+    }
+private:
+    srx_package* pkg_ = nullptr;
+};
+
+class RayEngine {                                                // Core.h:36-48
+public:
+    explicit RayEngine(int device = 0, uint64_t ray_capacity = 1u << 22) : capacity_(ray_capacity) { check(srx_init(device), "srx_init"); }
+    ~RayEngine() { srx_renderer_destroy(renderer_); srx_scene_destroy(scene_); }
+    RayEngine(const RayEngine&) = delete;
+    RayEngine& operator=(const RayEngine&) = delete;
+
+    void load_scene(const PackagedScene* PS) {                   // Core.h:46-48
+        srx_renderer_destroy(renderer_); renderer_ = nullptr;
+        srx_scene_destroy(scene_); scene_ = nullptr;
+        const srx_scene_desc d = PS->desc();
+        check(srx_scene_create(&d, &scene_), "srx_scene_create");
+    }
+    // Core.h:346 — `position` is advanced in place like the reference (o += t*d*0.999f, even on a miss).
+    CastResults execute_ray_cast(XYZ& position, const XYZ& slope) {
+        srx_hit h;
+        float adv[3];
+        check(srx_cast_closest(scene_, &position.X, &slope.X, 1, &h, adv, nullptr), "srx_cast_closest");
+        position = XYZ{adv[0], adv[1], adv[2]};
+        return to_results(h);
+    }
+    void execute_ray_cast_batch(const float* org3, const float* dir3, uint32_t n, srx_hit* hits, float* advanced = nullptr) {
+        check(srx_cast_closest(scene_, org3, dir3, n, hits, advanced, nullptr), "srx_cast_closest");
+    }
+    bool execute_lighting_cast(XYZ position, const SunLight& L) {   // Core.h:351-358
+        uint8_t lit = 0;
+        check(srx_cast_shadow(scene_, &position.X, &L.rotation.X, 1, &lit), "srx_cast_shadow");
+        return lit != 0;
+    }
+    // Core.h:359-601 — ray_data.key selects the ray's random stream (the reference uses a thread-local generator).
+    XYZ process_ray(Casting_Diagnostics& stats, PackagedRay& ray_data) {
+        float rad[3];
+        srx_counters c;
+        check(srx_process_rays(renderer(), &ray_data.position.X, &ray_data.slope.X, &ray_data.key, ray_data.generation, 1, rad, &c),
+              "srx_process_rays");
+        stats.rays_processed += (long long)c.rays_processed;
+        stats.diffuses_cast += (long)c.diffuses_cast;
+        stats.shadows_cast += (long)c.shadows_cast;
+        return XYZ{rad[0] * ray_data.coefficient.X, rad[1] * ray_data.coefficient.Y, rad[2] * ray_data.coefficient.Z};
+    }
+    // RenderThread::process_iteratively (SceneManager.h:193-237) for a rectangle: device framebuffers.
+    srx_counters trace_pass(const srx_camera& cam, int x0, int y0, int w, int h, uint32_t pass, uint64_t seed, float* d_accum4, float* d_aux4) {
+        srx_counters c;
+        check(srx_trace_pass(renderer(), &cam, x0, y0, w, h, pass, seed, d_accum4, d_aux4, &c), "srx_trace_pass");
+        return c;
+    }
+    srx_scene* scene() const { return scene_; }
+
+private:
+    srx_renderer* renderer() {
+        if (!renderer_) check(srx_renderer_create(scene_, capacity_, &renderer_), "srx_renderer_create");
+        return renderer_;
+    }
+    static CastResults to_results(const srx_hit& h) {
+        CastResults r;
+        r.material = h.material;
+        if (h.material != 0xFFFFFFFFu) { r.distance = h.t; r.TUV = XYZ{h.t, h.u, h.v}; }
+        r.tri_index = h.tri_index;
+        return r;
+    }
+    srx_scene* scene_ = nullptr;
+    srx_renderer* renderer_ = nullptr;
+    uint64_t capacity_;
+};
+
+}  // namespace spatialray

@@ -80,3 +80,11 @@ def test_slabs_partition_the_frame():
             for (a0, a1), (b0, b1) in zip(cuts, cuts[1:]):
                 assert a1 == b0 and a0 <= a1
             assert all(y0 % tiles.TILE == 0 for y0, _ in cuts)
+
+
+def test_cpp_adapter_header_compiles():
+    """include/spatialray_adapter.hpp (the reference-side binding of INTEGRATION.md) must compile as plain C++17."""
+    import subprocess
+    src = '#include "spatialray_adapter.hpp"\nint main() { spatialray::RayEngine* r = nullptr; (void)r; return 0; }\n'
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-x", "c++", "-"],
+                   input=src.encode(), check=True)
