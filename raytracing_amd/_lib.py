@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsrx.so")
+LIB_PATH = os.environ.get("SRX_LIB", os.path.join(HERE, "libsrx.so"))
 
 # every symbol include/srx.h declares; tests check the library exports all of them
 EXPORTS = [
