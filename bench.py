@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--res", type=str, default="1920x1080")
     ap.add_argument("--ray-capacity", type=int, default=1 << 27)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=str, default="480x270", help="centre crop of the frame timed on the host cores")
+    ap.add_argument("--cpu-sample", type=str, default="1920x1080", help="centre crop of the frame timed on the host cores")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20241111)
     return ap.parse_args()
@@ -182,6 +182,8 @@ def main():
                 "avg_launch_ms": trace_ms / launches,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
                 "bytes_per_ray": alg_bytes / max(1.0, rays),
+                "node_tests_per_ray": agg["nodes"] / max(1.0, rays),
+                "packet_tests_per_ray": agg["packets"] / max(1.0, rays),
                 "kernel_ms": {"trace": trace_ms, "shadow": shadow_ms, "shade": shade_ms, "wall": dt * 1e3},
             },
         }

@@ -1,12 +1,16 @@
 // raytracing_amd/csrc/srx_device.h — device-side layouts and arithmetic for the trace-and-shade path.
 //
 // HBM layouts (all immutable after srx_scene_create):
+//   geom    ONE allocation of 128-B lines: all nodes (2 lines each), then all packets (3 lines each). A link
+//           is a line index into it, bit 31 set for a leaf's first packet: the byte offset of a lane's 16-B
+//           slot is (link << 7) | (lane << 4), one VALU op, and the load uses one SGPR base for both kinds.
 //   GNode   256 B = two 128-B lines. Line A: 8 x {min.x, min.y, min.z, max.x}; line B: 8 x
-//           {max.y, max.z, link, 0}; link = (packets_in_leaf << 24) | index, packets==0 => inner child.
+//           {max.y, max.z, link, 0}; link == 0 => unused child slot (the root is never a child).
 //           One octet (8 adjacent lanes = the reference's 8 AVX lanes, BVH.h:874-881) reads a node with
 //           two dwordx4 loads per lane, each load covering one contiguous 128-B line per octet.
 //   GPacket 384 B = three 128-B lines: 8 x {p1.x,p1.y,p1.z,e1.x} | 8 x {e1.y,e1.z,e2.x,e2.y} |
-//           8 x {e2.z, material, tri_index, 0}; e1 = p1p2, e2 = p1p3 (Primitives.h:127-134).
+//           8 x {e2.z, material, tri_index, more}; e1 = p1p2, e2 = p1p3 (Primitives.h:127-134); more != 0
+//           when the next packet belongs to the same leaf (Core.h:179 walks leaf_size packets).
 //   GTri    160 B = ten 16-B rows with what shading reads of PackagedTri (Primitives.h:62-81).
 // Arithmetic: compiled with -ffp-contract=off; an FMA appears only where the reference has an FMA
 // intrinsic (__fmaf_rn), min/max follow x86 vminps/vmaxps operand order (second operand on NaN).
@@ -15,8 +19,8 @@
 #include <stdint.h>
 
 #define SRX_MISS_DISTANCE 99999999999999999.f   // Coredefs.cpp:9
-#define SRX_LINK_COUNT_SHIFT 24
-#define SRX_LINK_INDEX_MASK 0x00FFFFFFu
+#define SRX_LINK_LEAF 0x80000000u
+#define SRX_LINK_LINE_MASK 0x01FFFFFFu       // 2^25 lines of 128 B = 4 GB of nodes + packets
 
 struct GNode { float4 a[8]; float4 b[8]; };
 struct GPacket { float4 a[8]; float4 b[8]; float4 c[8]; };
@@ -51,8 +55,7 @@ struct GTexture {        // Texture.h:69-75
 struct GSun { float dir[3]; float emission[3]; };
 
 struct GScene {
-    const GNode* nodes;
-    const GPacket* packets;
+    const char* geom;             // nodes then packets, 128-B lines (see above)
     const GTri* tris;
     const GMaterial* materials;
     const GTexture* textures;

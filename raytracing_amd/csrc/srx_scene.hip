@@ -70,8 +70,8 @@ int stack_bound(const uint8_t* nodes, uint32_t n_nodes) {
 extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     if (!desc || !out) SRX_FAIL("srx_scene_create: null argument");
     if (desc->n_nodes == 0 || !desc->nodes) SRX_FAIL("srx_scene_create: scene has no BVH nodes");
-    if (desc->n_nodes > SRX_LINK_INDEX_MASK || desc->n_packets > SRX_LINK_INDEX_MASK)
-        SRX_FAIL("srx_scene_create: more than 2^24-1 nodes or packets is not supported");
+    if (2ull * desc->n_nodes + 3ull * desc->n_packets > (unsigned long long)SRX_LINK_LINE_MASK)
+        SRX_FAIL("srx_scene_create: nodes + packets exceed 4 GB (2^25 lines of 128 B)");
     if (desc->max_generations < 0 || desc->max_generations >= 32) SRX_FAIL("srx_scene_create: max_generations must be in [0, 31]");
     srx_scene* s = new srx_scene();
     SRX_HIP(hipGetDevice(&s->device));
@@ -82,17 +82,30 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     const uint8_t* rt = (const uint8_t*)desc->tris;
 
     // ---- nodes: 288-B SoA record (BVH.h:874-881) -> two 128-B child-major lines
+    // more[j]: 1 = packet j+1 continues the same leaf, 0 = last packet of its leaf, 2 = not referenced (yet)
+    std::vector<uint8_t> more(desc->n_packets, 2);
     std::vector<GNode> nodes(desc->n_nodes);
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const uint8_t* nd = rn + (size_t)i * SRX_REF_NODE_BYTES;
         for (int k = 0; k < 8; k++) {
             const uint32_t leaf = rdu(nd, 192 + 4 * k), idx = rdu(nd, 224 + 4 * k);
-            if (leaf > 255u) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: a leaf with more than 255 packets is not supported"); }
-            if (idx > SRX_LINK_INDEX_MASK || (leaf == 0 && idx >= desc->n_nodes) || (leaf > 0 && idx + leaf > desc->n_packets)) {
+            if ((leaf == 0 && idx >= desc->n_nodes) || (leaf > 0 && ((uint64_t)idx + leaf > desc->n_packets))) {
                 srx_scene_destroy(s); SRX_FAIL("srx_scene_create: node child index out of range");
             }
+            uint32_t link = 0;                                        // unused slot (BVH.h:890-895)
+            if (leaf == 0 && idx != 0) link = 2u * idx;
+            if (leaf > 0) {
+                link = SRX_LINK_LEAF | (2u * desc->n_nodes + 3u * idx);
+                for (uint32_t j = 0; j < leaf; j++) {
+                    const uint8_t want = (j + 1 < leaf) ? 1 : 0;
+                    if (more[idx + j] != 2 && more[idx + j] != want) {
+                        srx_scene_destroy(s); SRX_FAIL("srx_scene_create: leaves with overlapping packet ranges are not supported");
+                    }
+                    more[idx + j] = want;
+                }
+            }
             nodes[i].a[k] = make_float4(rdf(nd, 96 + 4 * k), rdf(nd, 128 + 4 * k), rdf(nd, 160 + 4 * k), rdf(nd, 0 + 4 * k));
-            nodes[i].b[k] = make_float4(rdf(nd, 32 + 4 * k), rdf(nd, 64 + 4 * k), u2f_host((leaf << SRX_LINK_COUNT_SHIFT) | idx), 0.0f);
+            nodes[i].b[k] = make_float4(rdf(nd, 32 + 4 * k), rdf(nd, 64 + 4 * k), u2f_host(link), 0.0f);
         }
     }
     // ---- packets: 448-B record (Primitives.h:127-134) -> three 128-B lanes-major lines
@@ -106,7 +119,7 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
             const float e2x = rdf(pk, 192 + 4 * k), e2y = rdf(pk, 224 + 4 * k), e2z = rdf(pk, 256 + 4 * k);
             packets[i].a[k] = make_float4(p1x, p1y, p1z, e1x);
             packets[i].b[k] = make_float4(e1y, e1z, e2x, e2y);
-            packets[i].c[k] = make_float4(e2z, u2f_host(rdu(pk, 384 + 4 * k)), u2f_host((uint32_t)(index + k)), 0.0f);
+            packets[i].c[k] = make_float4(e2z, u2f_host(rdu(pk, 384 + 4 * k)), u2f_host((uint32_t)(index + k)), u2f_host(more[i] == 1 ? 1u : 0u));
         }
     }
     // ---- shading triangles: the 160 bytes of PackagedTri (Primitives.h:62-81) that process_ray reads
@@ -124,8 +137,16 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
             srx_scene_destroy(s); SRX_FAIL("srx_scene_create: triangle material index out of range");
         }
     }
-    if (upload(s, nodes.data(), nodes.size(), &g.nodes)) { srx_scene_destroy(s); return 1; }
-    if (upload(s, packets.data(), packets.size(), &g.packets)) { srx_scene_destroy(s); return 1; }
+    {   // one allocation: node lines, then packet lines
+        const size_t nb = nodes.size() * sizeof(GNode), pb = packets.size() * sizeof(GPacket);
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, std::max<size_t>(nb + pb, 128));
+        if (e == hipSuccess) s->allocations.push_back(d);
+        if (e == hipSuccess && nb) e = hipMemcpy(d, nodes.data(), nb, hipMemcpyHostToDevice);
+        if (e == hipSuccess && pb) e = hipMemcpy((char*)d + nb, packets.data(), pb, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { srx_scene_destroy(s); SRX_FAIL(std::string("srx_scene_create: geometry upload: ") + hipGetErrorString(e)); }
+        g.geom = (const char*)d;
+    }
     if (upload(s, tris.data(), tris.size(), &g.tris)) { srx_scene_destroy(s); return 1; }
     g.n_nodes = desc->n_nodes; g.n_packets = desc->n_packets; g.n_tris = desc->n_tris;
 

@@ -30,7 +30,6 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
 }
 #define DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
 #define DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
-#define DPP_XOR3 0x1B          // quad_perm [3,2,1,0]
 #define DPP_HALF_MIRROR 0x141  // row_half_mirror
 
 __device__ __forceinline__ uint32_t octet_min_u32(uint32_t v) {
@@ -39,30 +38,68 @@ __device__ __forceinline__ uint32_t octet_min_u32(uint32_t v) {
     v = min(v, dpp_u32<DPP_HALF_MIRROR>(v));
     return v;
 }
-// number of the 7 other lanes of the octet whose key is smaller than this lane's
+// Number of the 7 other lanes of the octet whose key is smaller than this lane's. The subtract takes its first
+// operand through DPP and leaves "other < mine" in the borrow, which the add-with-carry folds into the count:
+// 2 VALU ops per neighbour (the compiler's form is mov_dpp + cmp + addc). The s_nop pairs are the gfx950 wait
+// states between a VALU write of VCC / of a DPP source and its VALU read; the assembler is not told about them
+// inside an asm block.
 __device__ __forceinline__ int octet_rank_u32(uint32_t ord) {
-    const uint32_t h = dpp_u32<DPP_HALF_MIRROR>(ord);
-    int rank = (dpp_u32<DPP_XOR1>(ord) < ord) + (dpp_u32<DPP_XOR2>(ord) < ord) + (dpp_u32<DPP_XOR3>(ord) < ord);
-    rank += (h < ord) + (dpp_u32<DPP_XOR1>(h) < ord) + (dpp_u32<DPP_XOR2>(h) < ord) + (dpp_u32<DPP_XOR3>(h) < ord);
-    return rank;
+    uint32_t rank = 0, h, t;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp %1, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_sub_co_u32_dpp %2, vcc, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_sub_co_u32_dpp %2, vcc, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_sub_co_u32_dpp %2, vcc, %3, %3 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_cmp_lt_u32_e32 vcc, %1, %3\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_sub_co_u32_dpp %2, vcc, %1, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_sub_co_u32_dpp %2, vcc, %1, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_sub_co_u32_dpp %2, vcc, %1, %3 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        : "+v"(rank), "=&v"(h), "=&v"(t) : "v"(ord) : "vcc");
+    return (int)rank;
 }
 
 // x86 vminps/vmaxps return the SECOND operand when either is NaN. FAST (no NaN can occur: every ray of the wave
 // has finite 1/d and -o/d, so the slab FMAs give finite or infinite values only) uses the hardware min/max
 // (v_min3/v_max3), which agree except for the sign of a zero result; a zero result is "no hit" either way.
-template <bool FAST> __device__ __forceinline__ float x86_min(float a, float b) { return FAST ? __builtin_fminf(a, b) : (a < b ? a : b); }
-template <bool FAST> __device__ __forceinline__ float x86_max(float a, float b) { return FAST ? __builtin_fmaxf(a, b) : (a > b ? a : b); }
+// The hardware forms are written as asm: through fminf/fmaxf the compiler adds a canonicalising v_max x,x per input.
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float x86_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float x86_max(float a, float b) { return a > b ? a : b; }
 
-// One child box per lane (BVH.h:940-988) + ordering key (Core.h:74-78). Returns the raw result bits (tmin or 0).
+// One child box per lane (BVH.h:940-988). Returns the raw result bits (tmin or 0).
 template <bool FAST>
 __device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, const f3 inv, const f3 fused) {
     const float tx1 = __fmaf_rn(A.x, inv.x, fused.x), tx2 = __fmaf_rn(A.w, inv.x, fused.x);
     const float ty1 = __fmaf_rn(A.y, inv.y, fused.y), ty2 = __fmaf_rn(B.x, inv.y, fused.y);
     const float tz1 = __fmaf_rn(A.z, inv.z, fused.z), tz2 = __fmaf_rn(B.y, inv.z, fused.z);
-    const float tminx = x86_min<FAST>(tx1, tx2), tminy = x86_min<FAST>(ty1, ty2), tminz = x86_min<FAST>(tz1, tz2);
-    const float tmaxx = x86_max<FAST>(tx1, tx2), tmaxy = x86_max<FAST>(ty1, ty2), tmaxz = x86_max<FAST>(tz1, tz2);
-    const float tmin = x86_max<FAST>(tminz, x86_max<FAST>(tminy, tminx));
-    const float tmax = x86_min<FAST>(tmaxz, x86_min<FAST>(tmaxy, tmaxx));
+    float tmin, tmax;
+    if (FAST) {
+        tmin = hw_max3(hw_min(tz1, tz2), hw_min(ty1, ty2), hw_min(tx1, tx2));
+        tmax = hw_min3(hw_max(tz1, tz2), hw_max(ty1, ty2), hw_max(tx1, tx2));
+    } else {
+        const float tminx = x86_min(tx1, tx2), tminy = x86_min(ty1, ty2), tminz = x86_min(tz1, tz2);
+        const float tmaxx = x86_max(tx1, tx2), tmaxy = x86_max(ty1, ty2), tmaxz = x86_max(tz1, tz2);
+        tmin = x86_max(tminz, x86_max(tminy, tminx));
+        tmax = x86_min(tmaxz, x86_min(tmaxy, tmaxx));
+    }
     const bool hit = (tmax >= 0.0f) && (tmin < tmax);
     return hit ? f2u(tmin) : 0u;
 }
@@ -70,7 +107,7 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, co
 // MODE 0: closest hit.  MODE 1: shadow, API form (writes lit[]).  MODE 2: shadow, renderer queue form.
 template <int MODE>
 __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArgs a) {
-    // LDS: traversal stack [depth][32 octets] of (tmin bits << 32 | link), then one 16-B best-hit record per octet
+    // LDS: traversal stack [depth][octets of the block] of (tmin bits << 32 | link), then one 16-B best-hit record per octet
     extern __shared__ unsigned long long s_mem[];
     unsigned long long* const s_stack = s_mem;
     uint4* const s_best = (uint4*)(s_mem + (size_t)sc.stack_depth * SRX_OCTETS_PER_BLOCK);
@@ -78,6 +115,8 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const int oct = threadIdx.x >> 3;
     const int lane = threadIdx.x & 63;
     const int oct_shift = lane & ~7;
+    const uint32_t sub16 = (uint32_t)sub << 4;
+    const uint32_t zero_key_limit = sub == 0 ? 7u : 0u;
     // XCD-aware block -> ray-range map: blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), so
     // XCD x works on the x-th contiguous eighth of the queue (queue order follows pixel / parent order).
     // Speed only; any placement gives the same results.
@@ -125,29 +164,34 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             if (!(u2f((uint32_t)(e >> 32)) >= best_t)) { link = (uint32_t)e; go = true; break; }
         }
         if (go) {
-            const uint32_t cnt = link >> SRX_LINK_COUNT_SHIFT;
-            const uint32_t idx = link & SRX_LINK_INDEX_MASK;
-            const bool leaf = cnt != 0;
-            // node (2 lines) and packet (3 lines) fetches are issued together, before the two kinds part ways
-            const char* base = leaf ? (const char*)(sc.packets + idx) : (const char*)(sc.nodes + idx);
-            const float4 A = *(const float4*)(base + 16 * sub);
-            const float4 B = *(const float4*)(base + 128 + 16 * sub);
+            const bool leaf = (link & SRX_LINK_LEAF) != 0u;
+            // node (2 lines) and packet (3 lines) fetches are issued together, before the two kinds part ways;
+            // the shift drops the leaf bit: byte offset = line * 128 + lane * 16, off one SGPR base
+            const uint32_t off = (link << 7) | sub16;
+            const char* const rec = sc.geom + (size_t)off;
+            const float4 A = *(const float4*)rec;
+            const float4 B = *(const float4*)(rec + 128);
             if (!leaf) {
                 n_nodes++;
                 const uint32_t rb = fast ? node_test<true>(A, B, inv, fused) : node_test<false>(A, B, inv, fused);
-                // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id; result==0 (either sign) is "no hit";
-                // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86)
-                const bool allow = (rb & 0x7fffffffu) != 0u;
-                const uint32_t kb = allow ? ((rb & ~7u) | (uint32_t)sub) : 0u;
-                const bool valid = (kb & 0x7fffffffu) != 0u;
-                // total order of floats as unsigned ints (no NaN keys exist); invalid lanes sort last
-                const uint32_t ord = valid ? ((kb & 0x80000000u) ? ~kb : (kb | 0x80000000u)) : 0xFFFFFFFFu;
+                // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id. result==0 (either sign) is "no hit";
+                // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86): both together are
+                // |result| > (lane == 0 ? 7 : 0)
+                const uint32_t kb = (rb & ~7u) | (uint32_t)sub;
+                const bool valid = (rb & 0x7fffffffu) > zero_key_limit;
                 const unsigned long long bal = __ballot(valid);
                 const uint32_t vmask = (uint32_t)(bal >> oct_shift) & 0xFFu;
                 const int nvalid = __popc(vmask);
-                // Shadow casts only ask "is there a hit with 0 < t <= 9999": the answer does not depend on the visiting
-                // order (a box the reference culls is culled behind a hit it already has), so the sort is skipped.
-                const int rank = (MODE == 0) ? octet_rank_u32(ord) : __popc(vmask & ((1u << sub) - 1u));
+                int rank;
+                if (MODE == 0) {
+                    // total order of floats as unsigned ints (no NaN keys exist); invalid lanes sort last
+                    const uint32_t ord = valid ? (kb ^ ((uint32_t)((int32_t)kb >> 31) | 0x80000000u)) : 0xFFFFFFFFu;
+                    rank = octet_rank_u32(ord);
+                } else {
+                    // Shadow casts only ask "is there a hit with 0 < t <= 9999": the answer does not depend on the
+                    // visiting order (a box the reference culls is culled behind a hit it already has): no sort.
+                    rank = __popc(vmask & ((1u << sub) - 1u));
+                }
                 // push far -> near so the nearest child is popped first (Core.h:98-106); stored distance is the
                 // unmodified tmin
                 if (valid) s_stack[(sp + nvalid - rank) * SRX_OCTETS_PER_BLOCK + oct] = ((unsigned long long)rb << 32) | f2u(B.z);
@@ -156,10 +200,10 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 // ---- leaf: one packet of 8 triangles per trip, one triangle per lane (Primitives.h:159-202).
                 // The rest of a multi-packet leaf goes back on top with distance -inf: it is never culled, exactly
                 // like the reference's inner `for` over the leaf's packets (Core.h:179).
-                const float4 C = *(const float4*)(base + 256 + 16 * sub);
-                if (cnt > 1) {
+                const float4 C = *(const float4*)(rec + 256);
+                if (f2u(C.w) != 0u) {
                     sp++;
-                    if (sub == 0) s_stack[sp * SRX_OCTETS_PER_BLOCK + oct] = (0xFF800000ull << 32) | (((cnt - 1) << SRX_LINK_COUNT_SHIFT) | (idx + 1));
+                    if (sub == 0) s_stack[sp * SRX_OCTETS_PER_BLOCK + oct] = (0xFF800000ull << 32) | (link + 3u);
                 }
                 n_packets++;
                 const float e1x = A.w, e1y = B.x, e1z = B.y;
