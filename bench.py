@@ -8,8 +8,8 @@ Rays = process_ray invocations (primary + every bounce generation), the referenc
 (SceneManager.h:83-90); shadow rays are reported beside it. The scene, tables and framebuffers are resident
 in HBM before the timed region starts.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the frame is sharded by horizontal tile
-slabs with the scene replicated (strong scaling, total work fixed); no collective on the data path, one
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the frame is sharded by tile rows
+dealt round-robin over the ranks, with the scene replicated (strong scaling, total work fixed); no collective on the data path, one
 framebuffer all-gather over RCCL at the end of the timed region.
 
 Prints ONE JSON line on rank 0.
@@ -99,10 +99,10 @@ def main():
     RE.load_scene(PS)
     RE.set_timing(True, ray_capacity=args.ray_capacity)
 
-    # tile slab of this rank (horizontal band of tile rows)
+    # this rank's share of the frame: tile rows (4 pixel rows) dealt round-robin over the ranks
     from raytracing_amd import tiles
-    y_lo, y_hi = tiles.slab(rank, world, H)
-    rect = (0, y_lo, W, y_hi - y_lo)
+    rect = (0, 0, W, H)
+    share = (tiles.TILE, rank, world)
     accum = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
     aux = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
 
@@ -112,20 +112,20 @@ def main():
         torch.cuda.synchronize()
 
     for p in range(args.warmup):
-        RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity)
+        RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share)
     barrier()
     t0 = time.perf_counter()
     tot = {}
     for p in range(args.warmup, args.warmup + args.steps):
-        c = RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity)
+        c = RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share)
         for k, v in c.items():
             tot[k] = tot.get(k, 0) + v
     if world > 1:
         # the two exchange steps: noise statistics all-reduce (KBs) and framebuffer all-gather over xGMI
-        sums, mins = tiles.slab_noise_stats(accum, aux, H, W, y_lo, y_hi)
+        sums, mins = tiles.rows_noise_stats(accum, aux, H, W, tiles.interleaved_rows(rank, world, H))
         tiles.allreduce_noise_stats(sums, mins)
-        tiles.gather_framebuffer(accum, H, W)
-        tiles.gather_framebuffer(aux, H, W)
+        tiles.gather_framebuffer_interleaved(accum, H, W)
+        tiles.gather_framebuffer_interleaved(aux, H, W)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -164,7 +164,7 @@ def main():
             "config": {
                 "workload": f"procedural Sponza-class atrium, {args.tris} tris, {W}x{H}, 1 spp per step, max_generations 8, "
                             f"monte_carlo_max 32 (BASELINE.json configs[1])",
-                "parallelism": f"tile slabs x{world}, scene replicated",
+                "parallelism": f"interleaved tile rows x{world}, scene replicated",
                 "rays_per_step": rays / args.steps,
                 "shadow_rays_per_step": agg["shadows_cast"] / args.steps,
                 "ray_capacity": args.ray_capacity,

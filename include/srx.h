@@ -168,6 +168,15 @@ int srx_renderer_set_timing(srx_renderer* r, int enabled);
 int srx_trace_pass(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
                    uint32_t pass_index, uint64_t seed, float* d_accum4, float* d_aux4, srx_counters* counters);
 
+/* The same pass over this caller's share of the rectangle's rows: groups of `group_rows` rows dealt round-robin
+ * over `nparts` callers (one per GPU), this caller taking groups part, part + nparts, ...; the pixels of the other
+ * callers are not touched. The reference deals interleaved pixel blocks to its render threads the same way
+ * (SceneManager::assign_iterative_groups, SceneManager.h:441-459), which evens out cheap and expensive image
+ * regions. srx_trace_pass == group_rows h, part 0, nparts 1. Results per pixel do not depend on the split. */
+int srx_trace_pass_interleaved(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                               int32_t group_rows, int32_t part, int32_t nparts, uint32_t pass_index, uint64_t seed,
+                               float* d_accum4, float* d_aux4, srx_counters* counters);
+
 /* `process_ray` on an explicit batch of rays (host arrays): ray i starts at generation `generation`
  * with keyed RNG state keys[i]; radiance3[i] receives the returned XYZ. Used by parity tests. */
 int srx_process_rays(srx_renderer* r, const float* org3, const float* dir3, const uint64_t* keys, int32_t generation,

@@ -17,7 +17,7 @@ EXPORTS = [
     "srx_scene_create", "srx_scene_destroy", "srx_scene_stack_bound",
     "srx_cast_closest", "srx_cast_closest_device", "srx_cast_shadow", "srx_cast_shadow_device",
     "srx_renderer_create", "srx_renderer_destroy", "srx_renderer_set_timing",
-    "srx_trace_pass", "srx_process_rays", "srx_camera_rays",
+    "srx_trace_pass", "srx_trace_pass_interleaved", "srx_process_rays", "srx_camera_rays",
 ]
 
 

@@ -11,6 +11,8 @@
 //   GPacket 384 B = three 128-B lines: 8 x {p1.x,p1.y,p1.z,e1.x} | 8 x {e1.y,e1.z,e2.x,e2.y} |
 //           8 x {e2.z, material, tri_index, more}; e1 = p1p2, e2 = p1p3 (Primitives.h:127-134); more != 0
 //           when the next packet belongs to the same leaf (Core.h:179 walks leaf_size packets).
+//   texture RGB8 rows (Texture.h:147-159) -> RGBX8, 32x32-texel tiles of 4 KB, Z-order inside a tile: the texels
+//           around a hit point share a few 128-B lines whatever the direction of the UV gradient.
 //   GTri    160 B = ten 16-B rows with what shading reads of PackagedTri (Primitives.h:62-81).
 // Arithmetic: compiled with -ffp-contract=off; an FMA appears only where the reference has an FMA
 // intrinsic (__fmaf_rn), min/max follow x86 vminps/vmaxps operand order (second operand on NaN).
@@ -45,12 +47,12 @@ struct GMaterial {       // srx_material with texture ids resolved to table slot
     float ior;          int ior_tex;
     int use_normals;
 };
-struct GTexture {        // Texture.h:69-75
-    const uint8_t* data;
+struct GTexture {        // Texture.h:69-75; texels re-tiled on upload, see tex_texel() in srx_shade.hip
+    const uint32_t* data;         // RGBX8 texels: 32x32 tiles in row-major tile order, Morton order inside a tile
     int res_x, res_y;
     double U_multiplier, V_multiplier;
     int normal_transform;
-    int pad;
+    int tiles_x;                  // tiles per tile row = ceil(res_x / 32)
 };
 struct GSun { float dir[3]; float emission[3]; };
 

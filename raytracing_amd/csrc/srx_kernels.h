@@ -41,9 +41,17 @@ struct ShadeArgs {
 };
 
 extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hipStream_t stream);
-extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int y0, int w, int h, uint32_t pass_index, uint64_t seed,
-                                        GRay* rays, float* dir3, unsigned long long* keys, hipStream_t stream);
+// Rows of a pass: local row j of this caller is image row
+//   y0 + ((j / group) * nparts + part) * group + j % group
+// i.e. groups of `group` rows dealt round-robin over `nparts` callers (nparts == 1: the plain rectangle).
+struct GRows { int y0, group, nparts, part; };
+__host__ __device__ inline int srx_row_of(const GRows& m, int j) {
+    return m.y0 + ((j / m.group) * m.nparts + m.part) * m.group + (j % m.group);
+}
+// rays for local rows [j0, j0 + rows) x columns [x0, x0 + w)
+extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, uint32_t pass_index,
+                                        uint64_t seed, GRay* rays, float* dir3, unsigned long long* keys, hipStream_t stream);
 extern "C" hipError_t srx_launch_pack_rays(const float* org3, const float* dir3, const unsigned long long* keys, uint32_t n,
                                            GRay* rays, hipStream_t stream);
-extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int y0, int w, int h, uint32_t pass_index, float* sample3,
+extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int w, GRows rows_map, int rows, uint32_t pass_index, float* sample3,
                                             float* accum4, float* aux4, hipStream_t stream);

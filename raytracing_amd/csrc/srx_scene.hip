@@ -155,12 +155,23 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     for (uint32_t i = 0; i < desc->n_textures; i++) {
         const srx_texture& t = desc->textures[i];
         if (!t.rgb8 || t.width <= 0 || t.height <= 0) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: bad texture"); }
-        const uint8_t* d = nullptr;
-        if (upload(s, t.rgb8, (size_t)t.width * t.height * 3, &d)) { srx_scene_destroy(s); return 1; }
+        // RGB8 rows -> RGBX8 in 32x32 tiles, Z-order inside a tile (texels outside the image are never addressed)
+        const uint32_t tiles_x = ((uint32_t)t.width + 31u) / 32u, tiles_y = ((uint32_t)t.height + 31u) / 32u;
+        std::vector<uint32_t> tiled((size_t)tiles_x * tiles_y * 1024u, 0u);
+        auto spread5 = [](uint32_t v) { v = (v | (v << 4)) & 0x10Fu; v = (v | (v << 2)) & 0x133u; return (v | (v << 1)) & 0x155u; };
+        for (uint32_t y = 0; y < (uint32_t)t.height; y++) {
+            for (uint32_t x = 0; x < (uint32_t)t.width; x++) {
+                const uint8_t* px = t.rgb8 + ((size_t)y * t.width + x) * 3;
+                const size_t tile = (size_t)(y >> 5) * tiles_x + (x >> 5);
+                tiled[tile * 1024u + (spread5(x & 31u) | (spread5(y & 31u) << 1))] = px[0] | (px[1] << 8) | (px[2] << 16);
+            }
+        }
+        const uint32_t* d = nullptr;
+        if (upload(s, tiled.data(), tiled.size(), &d)) { srx_scene_destroy(s); return 1; }
         tex[i].data = d; tex[i].res_x = t.width; tex[i].res_y = t.height;
         tex[i].U_multiplier = (double)(float)(t.width * t.scale_x);
         tex[i].V_multiplier = (double)(float)(t.height * t.scale_y);
-        tex[i].normal_transform = t.normal_transform; tex[i].pad = 0;
+        tex[i].normal_transform = t.normal_transform; tex[i].tiles_x = (int)tiles_x;
     }
     if (upload(s, tex.data(), tex.size(), &g.textures)) { srx_scene_destroy(s); return 1; }
     g.n_textures = desc->n_textures;

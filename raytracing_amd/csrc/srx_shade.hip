@@ -121,8 +121,15 @@ struct MatSample {
     }
 };
 
-// Texture.h:245-258 + fetch_char_* :147-159 (row-major RGB8, V flipped, C-style wrap)
-__device__ __forceinline__ size_t tex_address(const GTexture& t, float U, float V) {
+// Texture.h:245-258 + fetch_char_* :147-159 (V flipped, C-style wrap); same texel as the reference's row-major
+// lookup, fetched from the Morton-tiled copy with one dword load.
+__device__ __forceinline__ uint32_t spread5(uint32_t v) {     // abcde -> 0a0b0c0d0e
+    v = (v | (v << 4)) & 0x10Fu;
+    v = (v | (v << 2)) & 0x133u;
+    v = (v | (v << 1)) & 0x155u;
+    return v;
+}
+__device__ __forceinline__ uint32_t tex_texel(const GTexture& t, float U, float V) {
     double dU = U, dV = V;
     dV = 1 - dV;
     const int lx = (int)(t.U_multiplier * dU);
@@ -131,16 +138,18 @@ __device__ __forceinline__ size_t tex_address(const GTexture& t, float U, float 
     int y = ly % t.res_y;
     x = (x < 0) * t.res_x + x;
     y = (y < 0) * t.res_y + y;
-    return ((size_t)(unsigned)y * (unsigned)t.res_x + (unsigned)x) * 3;
+    const uint32_t ux = (uint32_t)x, uy = (uint32_t)y;
+    const size_t tile = (size_t)(uy >> 5) * (uint32_t)t.tiles_x + (ux >> 5);
+    return t.data[tile * 1024u + (spread5(ux & 31u) | (spread5(uy & 31u) << 1))];
 }
 __device__ __forceinline__ f3 tex_xyz(const GTexture& t, float U, float V) {
-    const size_t a = tex_address(t, U, V);
-    const int r = t.data[a], g = t.data[a + 1], b = t.data[a + 2];
+    const uint32_t p = tex_texel(t, U, V);
+    const int r = (int)(p & 0xFFu), g = (int)((p >> 8) & 0xFFu), b = (int)((p >> 16) & 0xFFu);
     if (t.normal_transform) return f3((r - 128) / 127.0f, (g - 128) / 127.0f, (b - 128) / 127.0f);
     return f3(r / 255.0f, g / 255.0f, b / 255.0f);
 }
 __device__ __forceinline__ float tex_float(const GTexture& t, float U, float V) {
-    return t.data[tex_address(t, U, V)] / 255.0f;
+    return (int)(tex_texel(t, U, V) & 0xFFu) / 255.0f;
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
@@ -423,11 +432,11 @@ __device__ __forceinline__ f3 camera_slope(const GCamera& c, int px, int py, uin
     return apply_rotation(slope, c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 }
 
-__global__ __launch_bounds__(256) void k_raygen(GCamera c, int x0, int y0, int w, int h, uint32_t pass_index, uint64_t seed,
+__global__ __launch_bounds__(256) void k_raygen(GCamera c, int x0, int w, GRows rm, int j0, int rows, uint32_t pass_index, uint64_t seed,
                                                GRay* rays, float* dir3, unsigned long long* keys) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (uint32_t)(w * h)) return;
-    const int px = x0 + (int)(idx % (uint32_t)w), py = y0 + (int)(idx / (uint32_t)w);
+    if (idx >= (uint32_t)(w * rows)) return;
+    const int px = x0 + (int)(idx % (uint32_t)w), py = srx_row_of(rm, j0 + (int)(idx / (uint32_t)w));
     const uint64_t npix = (uint64_t)c.res_x * c.res_y;
     const uint32_t pixel = (uint32_t)py * c.res_x + px;
     KeyedGen g;
@@ -462,11 +471,11 @@ __global__ __launch_bounds__(256) void k_pack_rays(const float* org3, const floa
 // ---------------------------------------------------------------- accumulation (SceneManager.h:220-233)
 // accum4/aux4: float4 per pixel = (running mean rgb, sample count). A non-finite sample is skipped
 // (the reference redraws it); the aux buffer takes the odd passes (add_aux toggles per pass).
-__global__ __launch_bounds__(256) void k_accumulate(int res_x, int x0, int y0, int w, int h, uint32_t pass_index, float* sample3,
+__global__ __launch_bounds__(256) void k_accumulate(int res_x, int x0, int w, GRows rm, int rows, uint32_t pass_index, float* sample3,
                                                    float4* accum4, float4* aux4) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (uint32_t)(w * h)) return;
-    const int px = x0 + (int)(idx % (uint32_t)w), py = y0 + (int)(idx / (uint32_t)w);
+    if (idx >= (uint32_t)(w * rows)) return;
+    const int px = x0 + (int)(idx % (uint32_t)w), py = srx_row_of(rm, (int)(idx / (uint32_t)w));
     const size_t pixel = (size_t)py * res_x + px;
     const f3 res(sample3[3 * pixel], sample3[3 * pixel + 1], sample3[3 * pixel + 2]);
     sample3[3 * pixel] = 0.0f; sample3[3 * pixel + 1] = 0.0f; sample3[3 * pixel + 2] = 0.0f;
@@ -495,11 +504,11 @@ extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hip
     hipLaunchKernelGGL(k_shade, dim3((a.n + 255) / 256), dim3(256), 0, stream, sc, a);
     return hipGetLastError();
 }
-extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int y0, int w, int h, uint32_t pass_index, uint64_t seed,
-                                        GRay* rays, float* dir3, unsigned long long* keys, hipStream_t stream) {
-    const uint32_t n = (uint32_t)(w * h);
+extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, uint32_t pass_index,
+                                        uint64_t seed, GRay* rays, float* dir3, unsigned long long* keys, hipStream_t stream) {
+    const uint32_t n = (uint32_t)(w * rows);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, stream, c, x0, y0, w, h, pass_index, seed, rays, dir3, keys);
+    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, stream, c, x0, w, rows_map, j0, rows, pass_index, seed, rays, dir3, keys);
     return hipGetLastError();
 }
 extern "C" hipError_t srx_launch_pack_rays(const float* org3, const float* dir3, const unsigned long long* keys, uint32_t n,
@@ -508,11 +517,11 @@ extern "C" hipError_t srx_launch_pack_rays(const float* org3, const float* dir3,
     hipLaunchKernelGGL(k_pack_rays, dim3((n + 255) / 256), dim3(256), 0, stream, org3, dir3, keys, n, rays);
     return hipGetLastError();
 }
-extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int y0, int w, int h, uint32_t pass_index, float* sample3,
+extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int w, GRows rows_map, int rows, uint32_t pass_index, float* sample3,
                                             float* accum4, float* aux4, hipStream_t stream) {
-    const uint32_t n = (uint32_t)(w * h);
+    const uint32_t n = (uint32_t)(w * rows);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, stream, res_x, x0, y0, w, h, pass_index, sample3,
+    hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, stream, res_x, x0, w, rows_map, rows, pass_index, sample3,
                        (float4*)accum4, (float4*)aux4);
     return hipGetLastError();
 }

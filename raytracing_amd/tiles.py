@@ -2,7 +2,9 @@
 
 The reference divides work over threads by interleaved pixel blocks with the immutable scene shared
 (`SceneManager::assign_iterative_groups`, SceneManager.h:441-459; blocks at :944-950). Across GPUs the scene
-is replicated and each rank renders a horizontal slab of tile rows; nothing is exchanged on the data path.
+is replicated and each rank renders its share of the tile rows — dealt round-robin (`interleaved_rows`, the default,
+which evens out cheap and expensive image regions) or as one contiguous slab (`slab`); nothing is exchanged on the
+data path.
 Two collectives exist, both outside the per-sample loop:
 
 * `gather_framebuffer` — the reference's per-block copy into one output (`get_screen_update`,
@@ -32,6 +34,13 @@ def slabs(world: int, height: int, tile: int = TILE):
     return [slab(r, world, height, tile) for r in range(world)]
 
 
+def interleaved_rows(rank: int, world: int, height: int, tile: int = TILE) -> torch.Tensor:
+    """Image rows of `rank` when tile rows (groups of `tile` rows) are dealt round-robin: tile row t belongs to
+    rank t % world. Matches srx_trace_pass_interleaved(group_rows=tile, part=rank, nparts=world) over the frame."""
+    rows = torch.arange(height)
+    return rows[(rows // tile) % world == rank]
+
+
 def _is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -57,6 +66,25 @@ def gather_framebuffer(buf: torch.Tensor, height: int, width: int, tile: int = T
     return buf
 
 
+def gather_framebuffer_interleaved(buf: torch.Tensor, height: int, width: int, tile: int = TILE):
+    """In-place all-gather of a (height*width, C) framebuffer whose rank-owned interleaved rows are valid.
+    Each rank packs its rows, one all-gather moves the packed shares (padded to the largest), every rank unpacks."""
+    if not _is_dist():
+        return buf
+    world, rank = dist.get_world_size(), dist.get_rank()
+    view = buf.view(height, -1)
+    owned = [interleaved_rows(r, world, height, tile).to(buf.device) for r in range(world)]
+    most = max(len(o) for o in owned)
+    mine = torch.zeros((most, view.shape[1]), dtype=buf.dtype, device=buf.device)
+    mine[: len(owned[rank])] = view[owned[rank]]
+    everyone = torch.empty((world * most, view.shape[1]), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(everyone, mine)
+    for r in range(world):
+        if r != rank and len(owned[r]):
+            view[owned[r]] = everyone[r * most: r * most + len(owned[r])]
+    return buf
+
+
 def allreduce_noise_stats(sums: torch.Tensor, min_samples: torch.Tensor):
     """Combine adaptive-sampling statistics: `sums` (any shape, summed) and `min_samples` (minimum)."""
     if _is_dist():
@@ -70,11 +98,19 @@ def luminance(rgb: torch.Tensor):
     return 0.2126 * rgb[..., 0] + 0.7152 * rgb[..., 1] + 0.0722 * rgb[..., 2]
 
 
+def rows_noise_stats(accum4: torch.Tensor, aux4: torch.Tensor, height: int, width: int, rows: torch.Tensor):
+    """`slab_noise_stats` over an arbitrary set of owned rows."""
+    rows = rows.to(accum4.device)
+    return _noise_stats(accum4.view(height, width, 4)[rows], aux4.view(height, width, 4)[rows])
+
+
 def slab_noise_stats(accum4: torch.Tensor, aux4: torch.Tensor, height: int, width: int, y0: int, y1: int):
     """Per-pixel error |L - L_aux| / max(L^1.1, L) (SceneManager.h:566-579) summed over this rank's slab,
     plus the pixel count and the minimum sample count. Returns (sums[2], min_samples[1])."""
-    a = accum4.view(height, width, 4)[y0:y1]
-    x = aux4.view(height, width, 4)[y0:y1]
+    return _noise_stats(accum4.view(height, width, 4)[y0:y1], aux4.view(height, width, 4)[y0:y1])
+
+
+def _noise_stats(a: torch.Tensor, x: torch.Tensor):
     L, La = luminance(a[..., :3]), luminance(x[..., :3])
     denom = torch.maximum(L.clamp_min(0) ** 1.1, L).clamp_min(1e-12)
     err = (L - La).abs() / denom

@@ -46,3 +46,55 @@ def test_gather_and_allreduce_world2(H):
         assert ok
         assert np.allclose(sums, ref, rtol=1e-5)
         assert mins == [5.0]
+
+
+def _worker_interleaved(rank, world, port, H, W, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracing_amd import tiles
+    rows = tiles.interleaved_rows(rank, world, H)
+    full = torch.arange(H * W * 4, dtype=torch.float32).view(H * W, 4)
+    buf = torch.zeros_like(full)
+    buf.view(H, W * 4)[rows] = full.view(H, W * 4)[rows]
+    tiles.gather_framebuffer_interleaved(buf, H, W)
+    ok_gather = bool(torch.equal(buf, full))
+    acc = torch.rand(H * W, 4, generator=torch.Generator().manual_seed(1)) + 0.1
+    aux = torch.rand(H * W, 4, generator=torch.Generator().manual_seed(2)) + 0.1
+    acc[:, 3] = 7 + rank
+    sums, mins = tiles.rows_noise_stats(acc, aux, H, W, rows)
+    tiles.allreduce_noise_stats(sums, mins)
+    ref_sums, _ = tiles.slab_noise_stats(acc, aux, H, W, 0, H)
+    q.put((rank, ok_gather, sums.tolist(), mins.tolist(), ref_sums.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [16, 22])      # 22 rows -> 6 tile rows, the last one short; shares of 12 and 10 rows
+def test_interleaved_gather_and_allreduce_world2(H):
+    W, world, port = 5, 2, 31500 + os.getpid() % 2000 + H
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_interleaved, args=(r, world, port, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, sums, mins, ref in res:
+        assert ok
+        assert np.allclose(sums, ref, rtol=1e-5)
+        assert mins == [7.0]
+
+
+def test_interleaved_rows_partition_the_frame():
+    from raytracing_amd import tiles
+    for H in (1, 4, 17, 1080):
+        for world in (1, 2, 3, 8):
+            got = torch.cat([tiles.interleaved_rows(r, world, H) for r in range(world)])
+            assert sorted(got.tolist()) == list(range(H))
+            # the library's row map (srx_kernels.h srx_row_of): local row j -> y0 + ((j // g) * nparts + part) * g + j % g
+            for r in range(world):
+                rows = tiles.interleaved_rows(r, world, H).tolist()
+                g = tiles.TILE
+                assert rows == [((j // g) * world + r) * g + j % g for j in range(len(rows))]

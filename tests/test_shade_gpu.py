@@ -22,10 +22,12 @@ def _scenes():
         "cornell": lambda: scenes.cornell(64, 2, with_sun=True),
         "atrium": lambda: scenes.atrium(16384, res=(96, 54), subdiv=2, tex_size=64),
         "interior": lambda: scenes.interior(8000, res=(80, 45), subdiv=2, tex_size=64),
+        # 50x50 textures: not a multiple of the 32x32 Morton tile, exercises the padded tiles
+        "interior_npot": lambda: scenes.interior(6000, res=(64, 36), subdiv=2, tex_size=50),
     }
 
 
-@pytest.fixture(scope="module", params=["cornell", "atrium", "interior"])
+@pytest.fixture(scope="module", params=["cornell", "atrium", "interior", "interior_npot"])
 def loaded(request, tables):
     from oracle import sro
     from raytracing_amd import engine
@@ -137,3 +139,29 @@ def test_trace_pass_accumulation(loaded):
     _compare(a[:, :3], acc_c[:, :3])
     _compare(x[:, :3], aux_c[:, :3])
     assert int(cg["rays_processed"]) > w * h
+
+
+def test_interleaved_parts_compose_to_the_full_pass(loaded):
+    """srx_trace_pass_interleaved: the shares of 3 callers (tile rows dealt round-robin, a short last group) touch
+    disjoint pixels and together equal the single full-frame pass (same keyed streams per pixel; float atomics may
+    reorder a pixel's additions, hence the small tolerance)."""
+    import torch
+    name, desc, RE, S = loaded
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    full = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+    parts = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+    c_full = RE.trace_pass(cam, (0, 0, w, h), 2, 99, full)
+    rays = 0
+    for part in range(3):
+        before = parts.clone()
+        c = RE.trace_pass(cam, (0, 0, w, h), 2, 99, parts, interleave=(4, part, 3))
+        rays += int(c["rays_processed"])
+        touched = (parts[:, 3] != before[:, 3]).view(h, w).any(dim=1).cpu().numpy()
+        expect = np.array([(y // 4) % 3 == part for y in range(h)])
+        assert np.array_equal(touched, expect)
+    torch.cuda.synchronize()
+    assert rays == int(c_full["rays_processed"])
+    a, b = full.cpu().numpy(), parts.cpu().numpy()
+    assert np.array_equal(a[:, 3], b[:, 3])
+    assert np.allclose(a[:, :3], b[:, :3], rtol=1e-4, atol=1e-6)
