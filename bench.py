@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=str, default="1920x1080", help="centre crop of the frame timed on the host cores")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20241111)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: exchange staged through the host)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -83,9 +85,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible and there is no CPU path")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from raytracing_amd import engine, scenes
 
@@ -134,6 +141,8 @@ def main():
     vals = torch.tensor([float(tot[k]) for k in keys] + [tot["trace_ms"], tot["shadow_ms"], tot["shade_ms"], dt],
                         dtype=torch.float64, device="cuda")
     if world > 1:
+        if args.backend != "nccl":
+            vals = vals.cpu()
         mx = vals.clone()
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)

@@ -45,10 +45,25 @@ def _is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def _host_staged(fn, buf, *args):
+    """gloo moves host memory only: with that backend a device framebuffer is exchanged through a host copy
+    (CPU tests and single-GPU rehearsals; RCCL takes the device tensor as it is)."""
+    if buf.is_cuda and dist.get_backend() == "gloo":
+        host = buf.cpu()
+        fn(host, *args)
+        buf.copy_(host)
+        return buf
+    return fn(buf, *args)
+
+
 def gather_framebuffer(buf: torch.Tensor, height: int, width: int, tile: int = TILE):
     """In-place all-gather of a (height*width, C) framebuffer whose rank-local slab rows are valid."""
     if not _is_dist():
         return buf
+    return _host_staged(_gather_slabs, buf, height, width, tile)
+
+
+def _gather_slabs(buf, height, width, tile):
     world, rank = dist.get_world_size(), dist.get_rank()
     view = buf.view(height, -1)
     cuts = slabs(world, height, tile)
@@ -71,6 +86,10 @@ def gather_framebuffer_interleaved(buf: torch.Tensor, height: int, width: int, t
     Each rank packs its rows, one all-gather moves the packed shares (padded to the largest), every rank unpacks."""
     if not _is_dist():
         return buf
+    return _host_staged(_gather_interleaved, buf, height, width, tile)
+
+
+def _gather_interleaved(buf, height, width, tile):
     world, rank = dist.get_world_size(), dist.get_rank()
     view = buf.view(height, -1)
     owned = [interleaved_rows(r, world, height, tile).to(buf.device) for r in range(world)]
@@ -88,8 +107,8 @@ def gather_framebuffer_interleaved(buf: torch.Tensor, height: int, width: int, t
 def allreduce_noise_stats(sums: torch.Tensor, min_samples: torch.Tensor):
     """Combine adaptive-sampling statistics: `sums` (any shape, summed) and `min_samples` (minimum)."""
     if _is_dist():
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        dist.all_reduce(min_samples, op=dist.ReduceOp.MIN)
+        for t, op in ((sums, dist.ReduceOp.SUM), (min_samples, dist.ReduceOp.MIN)):
+            _host_staged(lambda x, op=op: dist.all_reduce(x, op=op), t)
     return sums, min_samples
 
 
