@@ -2,15 +2,18 @@
 //
 // HBM layouts (all immutable after srx_scene_create):
 //   geom    ONE allocation of 128-B lines: all nodes (2 lines each), then all packets (3 lines each). A link
-//           is a line index into it, bit 31 set for a leaf's first packet: the byte offset of a lane's 16-B
-//           slot is (link << 7) | (lane << 4), one VALU op, and the load uses one SGPR base for both kinds.
+//           is a line index into it (bits 0..24); bit 31 marks a leaf's packet and bits 25..30 count the
+//           packets of the leaf that follow it. The byte offset of a lane's 16-B slot is
+//           (link << 7) | (lane << 4), one VALU op (the shift drops the flag bits), and the load uses one SGPR
+//           base for both kinds.
 //   GNode   256 B = two 128-B lines. Line A: 8 x {min.x, min.y, min.z, max.x}; line B: 8 x
 //           {max.y, max.z, link, 0}; link == 0 => unused child slot (the root is never a child).
 //           One octet (8 adjacent lanes = the reference's 8 AVX lanes, BVH.h:874-881) reads a node with
 //           two dwordx4 loads per lane, each load covering one contiguous 128-B line per octet.
-//   GPacket 384 B = three 128-B lines: 8 x {p1.x,p1.y,p1.z,e1.x} | 8 x {e1.y,e1.z,e2.x,e2.y} |
-//           8 x {e2.z, material, tri_index, more}; e1 = p1p2, e2 = p1p3 (Primitives.h:127-134); more != 0
-//           when the next packet belongs to the same leaf (Core.h:179 walks leaf_size packets).
+//   GPacket 384 B = three 128-B lines: 8 x {p1.x,p1.y,p1.z,e1.x} | 8 x {e1.y,e1.z,e2.x,0} |
+//           8 x {e2.y,e2.z}, material[8], tri_index[8]; e1 = p1p2, e2 = p1p3 (Primitives.h:127-134). A test
+//           reads 16 + 12 + 8 = 36 B per lane, a node test 16 + 12 (the data-return path of the vector cache is the busiest unit of the trace
+//           kernel); material and tri_index are read once per ray, for the winning lane only.
 //   texture RGB8 rows (Texture.h:147-159) -> RGBX8, 32x32-texel tiles of 4 KB, Z-order inside a tile: the texels
 //           around a hit point share a few 128-B lines whatever the direction of the UV gradient.
 //   GTri    160 B = ten 16-B rows with what shading reads of PackagedTri (Primitives.h:62-81).
@@ -23,9 +26,11 @@
 #define SRX_MISS_DISTANCE 99999999999999999.f   // Coredefs.cpp:9
 #define SRX_LINK_LEAF 0x80000000u
 #define SRX_LINK_LINE_MASK 0x01FFFFFFu       // 2^25 lines of 128 B = 4 GB of nodes + packets
+#define SRX_LINK_MORE_SHIFT 25               // bits 25..30: packets of the same leaf after this one
+#define SRX_LINK_MORE_MAX 63u
 
 struct GNode { float4 a[8]; float4 b[8]; };
-struct GPacket { float4 a[8]; float4 b[8]; float4 c[8]; };
+struct GPacket { float4 a[8]; float4 b[8]; float2 c[8]; uint32_t material[8]; uint32_t tri_index[8]; };
 struct GTri {
     float4 r[10];
     // r0: UV_basis.xy, U_delta.xy      r1: V_delta.xy, material(bits), normal.x

@@ -82,8 +82,6 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     const uint8_t* rt = (const uint8_t*)desc->tris;
 
     // ---- nodes: 288-B SoA record (BVH.h:874-881) -> two 128-B child-major lines
-    // more[j]: 1 = packet j+1 continues the same leaf, 0 = last packet of its leaf, 2 = not referenced (yet)
-    std::vector<uint8_t> more(desc->n_packets, 2);
     std::vector<GNode> nodes(desc->n_nodes);
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const uint8_t* nd = rn + (size_t)i * SRX_REF_NODE_BYTES;
@@ -95,14 +93,8 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
             uint32_t link = 0;                                        // unused slot (BVH.h:890-895)
             if (leaf == 0 && idx != 0) link = 2u * idx;
             if (leaf > 0) {
-                link = SRX_LINK_LEAF | (2u * desc->n_nodes + 3u * idx);
-                for (uint32_t j = 0; j < leaf; j++) {
-                    const uint8_t want = (j + 1 < leaf) ? 1 : 0;
-                    if (more[idx + j] != 2 && more[idx + j] != want) {
-                        srx_scene_destroy(s); SRX_FAIL("srx_scene_create: leaves with overlapping packet ranges are not supported");
-                    }
-                    more[idx + j] = want;
-                }
+                if (leaf - 1u > SRX_LINK_MORE_MAX) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: a leaf with more than 64 packets (512 triangles) is not supported"); }
+                link = SRX_LINK_LEAF | ((leaf - 1u) << SRX_LINK_MORE_SHIFT) | (2u * desc->n_nodes + 3u * idx);
             }
             nodes[i].a[k] = make_float4(rdf(nd, 96 + 4 * k), rdf(nd, 128 + 4 * k), rdf(nd, 160 + 4 * k), rdf(nd, 0 + 4 * k));
             nodes[i].b[k] = make_float4(rdf(nd, 32 + 4 * k), rdf(nd, 64 + 4 * k), u2f_host(link), 0.0f);
@@ -118,8 +110,9 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
             const float e1x = rdf(pk, 96 + 4 * k), e1y = rdf(pk, 128 + 4 * k), e1z = rdf(pk, 160 + 4 * k);
             const float e2x = rdf(pk, 192 + 4 * k), e2y = rdf(pk, 224 + 4 * k), e2z = rdf(pk, 256 + 4 * k);
             packets[i].a[k] = make_float4(p1x, p1y, p1z, e1x);
-            packets[i].b[k] = make_float4(e1y, e1z, e2x, e2y);
-            packets[i].c[k] = make_float4(e2z, u2f_host(rdu(pk, 384 + 4 * k)), u2f_host((uint32_t)(index + k)), u2f_host(more[i] == 1 ? 1u : 0u));
+            packets[i].b[k] = make_float4(e1y, e1z, e2x, 0.0f);
+            packets[i].c[k] = make_float2(e2y, e2z); packets[i].material[k] = rdu(pk, 384 + 4 * k);
+            packets[i].tri_index[k] = (uint32_t)(index + k);
         }
     }
     // ---- shading triangles: the 160 bytes of PackagedTri (Primitives.h:62-81) that process_ray reads

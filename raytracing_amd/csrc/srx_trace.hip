@@ -86,7 +86,7 @@ __device__ __forceinline__ float x86_max(float a, float b) { return a > b ? a : 
 
 // One child box per lane (BVH.h:940-988). Returns the raw result bits (tmin or 0).
 template <bool FAST>
-__device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, const f3 inv, const f3 fused) {
+__device__ __forceinline__ uint32_t node_test(const float4 A, const float3 B, const f3 inv, const f3 fused) {
     const float tx1 = __fmaf_rn(A.x, inv.x, fused.x), tx2 = __fmaf_rn(A.w, inv.x, fused.x);
     const float ty1 = __fmaf_rn(A.y, inv.y, fused.y), ty2 = __fmaf_rn(B.x, inv.y, fused.y);
     const float tz1 = __fmaf_rn(A.z, inv.z, fused.z), tz2 = __fmaf_rn(B.y, inv.z, fused.z);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             const uint32_t off = (link << 7) | sub16;
             const char* const rec = sc.geom + (size_t)off;
             const float4 A = *(const float4*)rec;
-            const float4 B = *(const float4*)(rec + 128);
+            const float3 B = *(const float3*)(rec + 128);   // 12 of the slot's 16 bytes: {max.y, max.z, link} / {e1.y, e1.z, e2.x}
             if (!leaf) {
                 n_nodes++;
                 const uint32_t rb = fast ? node_test<true>(A, B, inv, fused) : node_test<false>(A, B, inv, fused);
@@ -200,14 +200,14 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 // ---- leaf: one packet of 8 triangles per trip, one triangle per lane (Primitives.h:159-202).
                 // The rest of a multi-packet leaf goes back on top with distance -inf: it is never culled, exactly
                 // like the reference's inner `for` over the leaf's packets (Core.h:179).
-                const float4 C = *(const float4*)(rec + 256);
-                if (f2u(C.w) != 0u) {
-                    sp++;
-                    if (sub == 0) s_stack[sp * SRX_OCTETS_PER_BLOCK + oct] = (0xFF800000ull << 32) | (link + 3u);
+                const float2 C = *(const float2*)(rec + 256 - 8 * sub);   // third line: 8 x {e2.y, e2.z}, 8-B slots
+                if ((link & (SRX_LINK_MORE_MAX << SRX_LINK_MORE_SHIFT)) != 0u) {
+                    sp++;   // next packet of the leaf: line + 3, one packet fewer to follow
+                    if (sub == 0) s_stack[sp * SRX_OCTETS_PER_BLOCK + oct] = (0xFF800000ull << 32) | (link + 3u - (1u << SRX_LINK_MORE_SHIFT));
                 }
                 n_packets++;
                 const float e1x = A.w, e1y = B.x, e1z = B.y;
-                const float e2x = B.z, e2y = B.w, e2z = C.x;
+                const float e2x = B.z, e2y = C.x, e2z = C.y;
                 // pvec = cross_avx(slope, p1p3) (VecLib.cpp:282-289)
                 const float c1 = d.z * e2y, c2 = d.x * e2z, c3 = d.y * e2x;
                 const float px = __fmaf_rn(d.y, e2z, -c1), py = __fmaf_rn(d.z, e2x, -c2), pz = __fmaf_rn(d.x, e2y, -c3);
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                         if (MODE == 0) {
                             const unsigned long long wb = __ballot(tb == m);
                             const int w = __ffs((int)((uint32_t)(wb >> oct_shift) & 0xFFu)) - 1;
-                            // the winning lane records (u, v, material, tri_index) for its octet
-                            if (sub == w) s_best[oct] = make_uint4(f2u(uu), f2u(vv), f2u(C.y), f2u(C.z));
+                            // the winning lane records (u, v, where its material and tri_index are) for its octet
+                            if (sub == w) s_best[oct] = make_uint4(f2u(uu), f2u(vv), off + 256u + 64u - 12u * (uint32_t)sub, 0u);
                         } else if (best_t <= 9999.0f) {
                             sp = -1;   // any occluder nearer than 9999 => shadowed (Primitives.h:44-50)
                         }
@@ -247,10 +247,13 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             GHit h;
             const bool hit = best_t < SRX_MISS_DISTANCE;
             const uint4 b = s_best[oct];
-            h.material = hit ? b.z : 0xFFFFFFFFu;
+            h.material = 0xFFFFFFFFu; h.tri_index = 0;
+            if (hit) {   // third line of the winning packet: ... material[8] at +64, tri_index[8] at +96
+                h.material = *(const uint32_t*)(sc.geom + (size_t)b.z);
+                h.tri_index = *(const int32_t*)(sc.geom + (size_t)b.z + 32);
+            }
             h.t = hit ? best_t : -1.0f;
             h.u = hit ? u2f(b.x) : -1.0f; h.v = hit ? u2f(b.y) : -1.0f;
-            h.tri_index = hit ? (int32_t)b.w : 0;
             a.hits[ray] = h;
             if (a.advanced_org3) {
                 const f3 p = o + (best_t * d) * 0.999f;
