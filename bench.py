@@ -50,6 +50,20 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(tris, res):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc needs its own
+    runs, so it cannot be collected inside the timed run); None when the workload differs from the profiled one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            t = json.load(fh)
+        w = t["workload"]
+        if w["tris"] == tris and w["res"] == res and w["max_generations"] == 8:
+            return float(t["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(desc, cam, crop, seed, threads):
     """Times the CPU restatement (oracle, reference RNG mode, std::thread workers over interleaved rows) on
     a bounded crop of the same frame. This is the only place bench.py touches oracle/."""
@@ -186,7 +200,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args.tris, args.res) if world == 1 else None,
+                "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, bytes per launch)",
                 "launches": int(launches),
                 "avg_launch_ms": trace_ms / launches,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,

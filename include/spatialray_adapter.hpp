@@ -110,6 +110,14 @@ public:
         check(srx_trace_pass(renderer(), &cam, x0, y0, w, h, pass, seed, d_accum4, d_aux4, &c), "srx_trace_pass");
         return c;
     }
+    // one GPU's share of the pass: row groups part, part + nparts, ... (SceneManager::assign_iterative_groups, SceneManager.h:441-459)
+    srx_counters trace_pass_interleaved(const srx_camera& cam, int x0, int y0, int w, int h, int group_rows, int part, int nparts,
+                                        uint32_t pass, uint64_t seed, float* d_accum4, float* d_aux4) {
+        srx_counters c{};
+        check(srx_trace_pass_interleaved(renderer(), &cam, x0, y0, w, h, group_rows, part, nparts, pass, seed, d_accum4, d_aux4, &c),
+              "srx_trace_pass_interleaved");
+        return c;
+    }
     srx_scene* scene() const { return scene_; }
 
 private:
