@@ -186,7 +186,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"procedural Sponza-class atrium, {args.tris} tris, {W}x{H}, 1 spp per step, max_generations 8, "
-                            f"monte_carlo_max 32 (BASELINE.json configs[1])",
+                            f"monte_carlo_max 32 ({'BASELINE.json configs[1]' if (args.tris, args.res) == (262144, '1920x1080') else 'configs[1] scaled'})",
                 "parallelism": f"interleaved tile rows x{world}, scene replicated",
                 "rays_per_step": rays / args.steps,
                 "shadow_rays_per_step": agg["shadows_cast"] / args.steps,

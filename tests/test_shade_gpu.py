@@ -23,11 +23,13 @@ def _scenes():
         "atrium": lambda: scenes.atrium(16384, res=(96, 54), subdiv=2, tex_size=64),
         "interior": lambda: scenes.interior(8000, res=(80, 45), subdiv=2, tex_size=64),
         # 50x50 textures: not a multiple of the 32x32 Morton tile, exercises the padded tiles
+        # C5 (BASELINE.json configs[4]): closed diffuse box + clutter, 16 generations, monte_carlo_max 1, no sun
+        "diffuse_box": lambda: scenes.diffuse_box(3000, res=(64, 36), subdiv=2),
         "interior_npot": lambda: scenes.interior(6000, res=(64, 36), subdiv=2, tex_size=50),
     }
 
 
-@pytest.fixture(scope="module", params=["cornell", "atrium", "interior", "interior_npot"])
+@pytest.fixture(scope="module", params=["cornell", "atrium", "interior", "diffuse_box", "interior_npot"])
 def loaded(request, tables):
     from oracle import sro
     from raytracing_amd import engine
