@@ -177,6 +177,42 @@ int srx_trace_pass_interleaved(srx_renderer* r, const srx_camera* camera, int32_
                                int32_t group_rows, int32_t part, int32_t nparts, uint32_t pass_index, uint64_t seed,
                                float* d_accum4, float* d_aux4, srx_counters* counters);
 
+/* ---- adaptive sampling: replaces SceneManager::analyze_noise (SceneManager.h:526-667), the
+ * priority half of SceneManager::balance_threads (:668-692) and the per-block visit rule of
+ * RenderThread::process_iteratively (:193-198). Blocks are the reference's 4x4 pixel blocks (:299), numbered
+ * row-major over ceil(res_x/4) x ceil(res_y/4). */
+typedef struct srx_noise srx_noise;
+typedef struct srx_noise_region {          /* SceneManager::noise_region, SceneManager.h:262-273 */
+    int32_t x0, y0, x1, y1;                /* start (inclusive), end (exclusive) */
+    int32_t active;
+    float noise, max_noise, min_noise, avg_noise;
+} srx_noise_region;
+
+/* one region covering the frame (SceneManager.h:937-938); minimum_samples < 0 = the reference's 64 (:301) */
+int srx_noise_create(int32_t res_x, int32_t res_y, uint64_t seed, int32_t minimum_samples, srx_noise** out);
+void srx_noise_destroy(srx_noise* c);
+/* device: d_err[pixel] = |L - L_aux| / max(L^1.1, L) (:568-572; 0 where L == 0) for the rows this caller owns
+ * (interleave as in srx_trace_pass_interleaved) and 0 elsewhere, so a sum over the callers completes the map;
+ * *min_samples = the smallest per-pixel sample count among the owned rows (:492-501). */
+int srx_noise_error_map(srx_noise* c, const float* d_accum4, const float* d_aux4, int32_t group_rows, int32_t part,
+                        int32_t nparts, float* d_err, int32_t* min_samples);
+/* analyze_noise on the complete error map (device pointer): region statistics on the device, split search and
+ * region list on the host. `seen` = minimum sample count over the whole frame. */
+int srx_noise_analyze(srx_noise* c, const float* d_err, int32_t seen);
+/* copies at most `capacity` regions, *count = how many exist */
+int srx_noise_regions(const srx_noise* c, srx_noise_region* out, uint32_t capacity, uint32_t* count);
+/* block priorities (:669-692) into d_block_priority (device, one float per block); all 1 while seen < minimum_samples
+ * (*updated = 0), as the reference leaves block::priority at its initial value (:36). */
+int srx_noise_priorities(srx_noise* c, int32_t seen, float* d_block_priority, int32_t* updated);
+
+/* One VISIT of every 4x4 block of this caller's rows (RenderThread::process_iteratively, SceneManager.h:193-237):
+ * a block takes floor(p) + [u < frac(p)] samples (0 or 1; p <= 1 by construction) with u keyed by (seed, visit_index,
+ * block); a pixel's sample index is its own count so far (block->iterations_done) and the aux buffer takes the odd
+ * ones (:226-233). d_block_priority NULL = all 1. With all priorities 1 and equal counts this is srx_trace_pass. */
+int srx_trace_pass_adaptive(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                            int32_t group_rows, int32_t part, int32_t nparts, uint32_t visit_index, uint64_t seed,
+                            const float* d_block_priority, float* d_accum4, float* d_aux4, srx_counters* counters);
+
 /* `process_ray` on an explicit batch of rays (host arrays): ray i starts at generation `generation`
  * with keyed RNG state keys[i]; radiance3[i] receives the returned XYZ. Used by parity tests. */
 int srx_process_rays(srx_renderer* r, const float* org3, const float* dir3, const uint64_t* keys, int32_t generation,

@@ -152,6 +152,21 @@ class OracleScene:
         return st
 
 
+def _render_pass_adaptive(self, camera, rect, visit_index, seed, accum4, aux4=None, block_priority=None, threads=1):
+    """One visit of every 4x4 block with per-block priorities (SceneManager.h:193-237), keyed RNG."""
+    cam = np.ascontiguousarray(camera)
+    x0, y0, w, h = rect
+    st = np.zeros(8, np.uint64)
+    pr = None if block_priority is None else np.ascontiguousarray(block_priority, np.float32)
+    self._chk(self.L.sro_render_pass_adaptive(self.h, _p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w), C.c_int32(h),
+                                              C.c_uint32(visit_index), C.c_uint64(seed), _p(pr), C.c_int32(threads),
+                                              _p(accum4), _p(aux4), _p(st)))
+    return st
+
+
+OracleScene.render_pass_adaptive = _render_pass_adaptive
+
+
 def camera_rays_keyed(camera, rect, pass_index, seed):
     cam = np.ascontiguousarray(camera)
     x0, y0, w, h = rect
@@ -187,3 +202,53 @@ def poly_acos(x):
     o = np.zeros_like(x)
     lib().sro_poly_acos(_p(x), C.c_uint32(len(x)), _p(o))
     return o
+
+
+# ---- adaptive-sampling controller (oracle/sro_noise.h) ------------------------------------------------------
+def noise_error_map(accum4, aux4):
+    """(err[npix], minimum sample count): SceneManager.h:566-572 per pixel, :492-501."""
+    a = np.ascontiguousarray(accum4, np.float32).reshape(-1, 4)
+    x = np.ascontiguousarray(aux4, np.float32).reshape(-1, 4)
+    err = np.zeros(len(a), np.float32)
+    mn = C.c_int32(0)
+    lib().sro_noise_error_map(_p(a), _p(x), C.c_uint64(len(a)), _p(err), C.byref(mn))
+    return err, mn.value
+
+
+def noise_block_fires(priority, seed, visit_index, block, n_blocks):
+    return bool(lib().sro_noise_block_fires(C.c_float(priority), C.c_uint64(seed), C.c_uint32(visit_index), C.c_uint32(block),
+                                            C.c_uint32(n_blocks)))
+
+
+class OracleNoise:
+    """SceneManager::analyze_noise / balance_threads (SceneManager.h:526-692) on the CPU."""
+
+    def __init__(self, res_x, res_y, seed, minimum_samples=64):
+        L = lib()
+        L.sro_noise_new.restype = C.c_void_p
+        L.sro_noise_region_count.restype = C.c_uint32
+        self.L, self.res_x, self.res_y = L, res_x, res_y
+        self.h = C.c_void_p(L.sro_noise_new(C.c_int32(res_x), C.c_int32(res_y), C.c_uint64(seed), C.c_int32(minimum_samples)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.sro_noise_free(self.h)
+            self.h = None
+
+    def analyze(self, err, seen):
+        e = np.ascontiguousarray(err, np.float32)
+        assert e.size == self.res_x * self.res_y
+        self.L.sro_noise_analyze(self.h, _p(e), C.c_int32(seen))
+
+    def regions(self):
+        n = self.L.sro_noise_region_count(self.h)
+        rects = np.zeros((n, 4), np.int32)
+        stats = np.zeros((n, 5), np.float32)
+        self.L.sro_noise_regions(self.h, _p(rects), _p(stats))
+        return rects, stats
+
+    def priorities(self, seen):
+        bx, by = (self.res_x + 3) // 4, (self.res_y + 3) // 4
+        out = np.ones(bx * by, np.float32)
+        wrote = self.L.sro_noise_priorities(self.h, C.c_int32(seen), _p(out))
+        return out, bool(wrote)

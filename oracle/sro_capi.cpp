@@ -4,6 +4,7 @@
 // bench.py's cpu_baseline leg can drive it through ctypes. The product never
 // links or loads this library. PARITY UNPINNED (see sro_math.h).
 #include "sro_shade.h"
+#include "sro_noise.h"
 #include <chrono>
 #include <thread>
 #include <atomic>
@@ -310,6 +311,107 @@ int sro_render_pass(void* hv, const sro_camera_in* c, int32_t x0, int32_t y0, in
                         cur *= (float)((double)n / (n + 1));
                         cur += (float)(1.0 / (n + 1)) * res;
                         a[0] = cur.X; a[1] = cur.Y; a[2] = cur.Z; a[3] = (float)(n + 1);
+                    }
+                }
+            }
+        } catch (const std::exception& e) { failed = 1; }
+    };
+    if (threads == 1) worker(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back(worker, t);
+        for (auto& t : pool) t.join();
+    }
+    if (failed) { g_err = "oracle render worker failed"; return 1; }
+    if (stats8) {
+        for (int i = 0; i < 8; i++) stats8[i] = 0;
+        for (auto& s : st) {
+            stats8[0] += s.rays_processed; stats8[1] += s.diffuses_cast; stats8[2] += s.shadows_cast;
+            stats8[3] += s.trace.nodes; stats8[4] += s.trace.packets;
+            stats8[5] += s.shadow_trace.nodes; stats8[6] += s.shadow_trace.packets; stats8[7] += s.hits;
+        }
+    }
+    return 0;
+}
+
+// ---- adaptive-sampling controller (SceneManager.h:526-692) ------------------
+void sro_noise_error_map(const float* accum4, const float* aux4, uint64_t npix, float* err, int32_t* min_samples) {
+    int mn = npix ? (int)accum4[3] : 0;
+    for (uint64_t i = 0; i < npix; i++) {
+        err[i] = noise_pixel_error(accum4 + 4 * i, aux4 + 4 * i);
+        mn = std::min(mn, (int)accum4[4 * i + 3]);
+    }
+    if (min_samples) *min_samples = mn;
+}
+void* sro_noise_new(int32_t res_x, int32_t res_y, uint64_t seed, int32_t minimum_samples) {
+    NoiseController* c = new NoiseController();
+    c->reset(res_x, res_y, seed);
+    if (minimum_samples >= 0) c->minimum_samples = minimum_samples;
+    return c;
+}
+void sro_noise_free(void* c) { delete (NoiseController*)c; }
+void sro_noise_analyze(void* cv, const float* err, int32_t seen) { ((NoiseController*)cv)->analyze(err, seen); }
+uint32_t sro_noise_region_count(void* cv) { return (uint32_t)((NoiseController*)cv)->regions.size(); }
+// rects4: x0,y0,x1,y1 per region; stats5: active, noise, max_noise, min_noise, avg_noise
+void sro_noise_regions(void* cv, int32_t* rects4, float* stats5) {
+    NoiseController* c = (NoiseController*)cv;
+    for (size_t i = 0; i < c->regions.size(); i++) {
+        const NoiseRegion& r = c->regions[i];
+        rects4[4 * i] = r.x0; rects4[4 * i + 1] = r.y0; rects4[4 * i + 2] = r.x1; rects4[4 * i + 3] = r.y1;
+        stats5[5 * i] = r.active ? 1.0f : 0.0f; stats5[5 * i + 1] = r.noise; stats5[5 * i + 2] = r.max_noise;
+        stats5[5 * i + 3] = r.min_noise; stats5[5 * i + 4] = r.avg_noise;
+    }
+}
+int32_t sro_noise_priorities(void* cv, int32_t seen, float* out) { return ((NoiseController*)cv)->priorities(seen, out) ? 1 : 0; }
+int32_t sro_noise_block_fires(float priority, uint64_t seed, uint32_t visit_index, uint32_t block, uint32_t n_blocks) {
+    return noise_block_fires(priority, seed, visit_index, block, n_blocks) ? 1 : 0;
+}
+
+// One visit of every 4x4 block of the rectangle (RenderThread::process_iteratively, SceneManager.h:193-237) with
+// per-block priorities (NULL = all 1): a block that fires takes one keyed sample per pixel; the sample index of a
+// pixel is its own count so far (block->iterations_done), the aux buffer takes the odd ones (:226-233).
+int sro_render_pass_adaptive(void* hv, const sro_camera_in* c, int32_t x0, int32_t y0, int32_t w, int32_t hgt,
+                             uint32_t visit_index, uint64_t seed, const float* block_priority, int32_t threads,
+                             float* accum4, float* aux4, uint64_t* stats8) {
+    Handle* h = (Handle*)hv;
+    Camera cam = make_camera(c);
+    const uint64_t npix = (uint64_t)c->res_x * c->res_y;
+    const int spp = c->subdiv * c->subdiv;
+    const int bs = NoiseController::block_size;
+    const uint32_t bxn = (uint32_t)((c->res_x + bs - 1) / bs), byn = (uint32_t)((c->res_y + bs - 1) / bs);
+    if (threads < 1) threads = 1;
+    std::vector<Diagnostics> st(threads);
+    std::atomic<int> failed{0};
+    auto worker = [&](int tid) {
+        try {
+            RayEngine RE; RE.data = &h->scene; RE.keyed = true;
+            for (int y = y0 + tid; y < y0 + hgt; y += threads) {
+                for (int x = x0; x < x0 + w; x++) {
+                    const uint32_t block = (uint32_t)(y / bs) * bxn + (uint32_t)(x / bs);
+                    const float pr = block_priority ? block_priority[block] : 1.0f;
+                    if (!noise_block_fires(pr, seed, visit_index, block, bxn * byn)) continue;
+                    float* o = accum4 + 4 * ((size_t)y * c->res_x + x);
+                    const int n = (int)o[3];
+                    PackagedRay ray;
+                    ray.position = cam.position;
+                    ray.generation = 0;
+                    KeyedGen g;
+                    g.s = KeyedGen::primary_key(seed, (uint64_t)n * npix + (uint64_t)y * c->res_x + x);
+                    ray.slope = cam.random_slope_at(x, y, n % spp, g);
+                    ray.key = g.s;
+                    XYZ res = RE.process_ray(st[tid], ray);
+                    if (!res.wellDefined()) continue;
+                    XYZ cur(o[0], o[1], o[2]);
+                    cur *= (float)((double)n / (n + 1));
+                    cur += (float)(1.0 / (n + 1)) * res;
+                    o[0] = cur.X; o[1] = cur.Y; o[2] = cur.Z; o[3] = (float)(n + 1);
+                    if (aux4 && (n & 1)) {
+                        float* a = aux4 + 4 * ((size_t)y * c->res_x + x);
+                        const int na = (int)a[3];
+                        XYZ ca(a[0], a[1], a[2]);
+                        ca *= (float)((double)na / (na + 1));
+                        ca += (float)(1.0 / (na + 1)) * res;
+                        a[0] = ca.X; a[1] = ca.Y; a[2] = ca.Z; a[3] = (float)(na + 1);
                     }
                 }
             }

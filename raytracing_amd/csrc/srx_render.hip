@@ -254,6 +254,50 @@ extern "C" int srx_trace_pass_interleaved(srx_renderer* r, const srx_camera* cam
     return end_call(r, counters);
 }
 
+extern "C" int srx_trace_pass_adaptive(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                                       int32_t group_rows, int32_t part, int32_t nparts, uint32_t visit_index, uint64_t seed,
+                                       const float* d_block_priority, float* d_accum4, float* d_aux4, srx_counters* counters) {
+    if (!r || !camera || !d_accum4) SRX_FAIL("srx_trace_pass_adaptive: null argument");
+    if (camera->res_x <= 0 || camera->res_y <= 0 || camera->subdiv <= 0) SRX_FAIL("srx_trace_pass_adaptive: bad camera");
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > camera->res_x || y0 + h > camera->res_y)
+        SRX_FAIL("srx_trace_pass_adaptive: rectangle outside the camera resolution");
+    if (group_rows <= 0 || nparts <= 0 || part < 0 || part >= nparts) SRX_FAIL("srx_trace_pass_adaptive: bad row interleave (group_rows, part, nparts)");
+    const uint64_t npix = (uint64_t)camera->res_x * camera->res_y;
+    if (npix > 0x00FFFFFFull) SRX_FAIL("srx_trace_pass_adaptive: more than 2^24-1 pixels is not supported");
+    if (ensure_sample_buffer(r, npix)) return 1;
+    if (begin_call(r)) return 1;
+    GCamera cam;
+    std::memcpy(&cam, camera, sizeof(cam));
+    GRows rm;
+    rm.y0 = y0; rm.group = group_rows; rm.nparts = nparts; rm.part = part;
+    int own_rows = 0;
+    for (int g0 = part * group_rows; g0 < h; g0 += nparts * group_rows) own_rows += std::min(group_rows, h - g0);
+    if (own_rows == 0) return end_call(r, counters);
+    AdaptiveArgs a;
+    a.block_priority = d_block_priority; a.accum4 = (const float4*)d_accum4; a.visit_index = visit_index; a.seed = seed;
+    a.blocks_x = (uint32_t)((camera->res_x + 3) / 4);
+    a.n_blocks = a.blocks_x * (uint32_t)((camera->res_y + 3) / 4);
+    const GScene& g = r->scene->g;
+    const uint64_t fan0 = (uint64_t)std::max(1, g.bounce_count[0]);
+    uint64_t band_rays = r->capacity / (1 + (g.max_generations > 0 ? fan0 : 0));
+    if (band_rays < (uint64_t)w) SRX_FAIL("srx_trace_pass_adaptive: ray_capacity too small for one pixel row and its first bounce");
+    const int band_rows = (int)std::min<uint64_t>((uint64_t)own_rows, band_rays / (uint64_t)w);
+    for (int j = 0; j < own_rows; j += band_rows) {
+        const int rows = std::min(band_rows, own_rows - j);
+        // primaries of the blocks that fire, appended compactly; their number comes back with an 8-byte copy
+        SRX_HIP(hipMemsetAsync(r->d_counts, 0, sizeof(DeviceCounts), r->stream));
+        SRX_HIP(srx_launch_raygen_adaptive(cam, x0, w, rm, j, rows, a, r->rays, &r->d_counts->out_count, r->stream));
+        SRX_HIP(hipMemcpyAsync(r->h_counts, r->d_counts, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
+        SRX_HIP(hipStreamSynchronize(r->stream));
+        const uint64_t n = r->h_counts->out_count;
+        if (n > (uint64_t)rows * w) SRX_FAIL("srx: internal error, more primaries than pixels");
+        r->top = n;
+        if (n && process_segment(r, 0, 0, n)) return 1;
+    }
+    SRX_HIP(srx_launch_accumulate_adaptive(camera->res_x, x0, w, rm, own_rows, a, r->sample3, d_accum4, d_aux4, r->stream));
+    return end_call(r, counters);
+}
+
 extern "C" int srx_trace_pass(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
                               uint32_t pass_index, uint64_t seed, float* d_accum4, float* d_aux4, srx_counters* counters) {
     return srx_trace_pass_interleaved(r, camera, x0, y0, w, h, h > 0 ? h : 1, 0, 1, pass_index, seed, d_accum4, d_aux4, counters);

@@ -455,6 +455,84 @@ __global__ __launch_bounds__(256) void k_raygen(GCamera c, int x0, int w, GRows 
     if (keys) keys[idx] = g.s;
 }
 
+// ---- adaptive visit (RenderThread::process_iteratively, SceneManager.h:193-237)
+// does block `block` take a sample on this visit? floor(p) + [u < frac(p)] > 0 with u keyed by (seed, visit, block)
+__device__ __forceinline__ bool block_fires(const AdaptiveArgs& a, uint32_t block) {
+    const float scaled = a.block_priority ? a.block_priority[block] : 1.0f;
+    KeyedGen g;
+    g.s = KeyedGen::mix(a.seed ^ KeyedGen::mix((uint64_t)a.visit_index * a.n_blocks + block + 0x2545F4914F6CDD1Dull) ^
+                        KeyedGen::mix(0x51ED270B0BADC0DEull + 0x9E6C63D0676A9A99ull));
+    const float u = g.fRand(0, 1);
+    const float fl = floorf(scaled);
+    const bool add_one = u < (scaled - fl);
+    return (int)((float)add_one + fl) > 0;
+}
+
+__global__ __launch_bounds__(256) void k_raygen_adaptive(GCamera c, int x0, int w, GRows rm, int j0, int rows, AdaptiveArgs a, GRay* rays,
+                                                        uint32_t* count) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_wave_count[4];
+    __shared__ uint32_t s_base;
+    bool fire = false;
+    int px = 0, py = 0;
+    uint32_t pixel = 0, n = 0;
+    if (idx < (uint32_t)(w * rows)) {
+        px = x0 + (int)(idx % (uint32_t)w); py = srx_row_of(rm, j0 + (int)(idx / (uint32_t)w));
+        pixel = (uint32_t)py * c.res_x + px;
+        fire = block_fires(a, (uint32_t)(py / 4) * a.blocks_x + (uint32_t)(px / 4));
+        if (fire) n = (uint32_t)(int)a.accum4[pixel].w;
+    }
+    // compaction: one queue reservation per workgroup
+    const unsigned long long bal = __ballot(fire);
+    if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; wv++) { const uint32_t cnt = s_wave_count[wv]; if (wv < wave) before += cnt; total += cnt; }
+    if (threadIdx.x == 0 && total) s_base = atomicAdd(count, total);
+    __syncthreads();
+    if (!fire) return;
+    const uint32_t slot = s_base + before + (uint32_t)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    const uint64_t npix = (uint64_t)c.res_x * c.res_y;
+    KeyedGen g;
+    g.s = KeyedGen::primary_key(a.seed, (uint64_t)n * npix + pixel);
+    const f3 d = camera_slope(c, px, py, n, g);
+    GRay r;
+    r.ox = c.pos[0]; r.oy = c.pos[1]; r.oz = c.pos[2];
+    r.dx = d.x; r.dy = d.y; r.dz = d.z;
+    r.cr = 1.0f; r.cg = 1.0f; r.cb = 1.0f;
+    r.pixel = pixel;
+    r.key_lo = (uint32_t)g.s; r.key_hi = (uint32_t)(g.s >> 32);
+    rays[slot] = r;
+}
+
+__global__ __launch_bounds__(256) void k_accumulate_adaptive(int res_x, int x0, int w, GRows rm, int rows, AdaptiveArgs a, float* sample3,
+                                                            float4* accum4, float4* aux4) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)(w * rows)) return;
+    const int px = x0 + (int)(idx % (uint32_t)w), py = srx_row_of(rm, (int)(idx / (uint32_t)w));
+    if (!block_fires(a, (uint32_t)(py / 4) * a.blocks_x + (uint32_t)(px / 4))) return;
+    const size_t pixel = (size_t)py * res_x + px;
+    const f3 res(sample3[3 * pixel], sample3[3 * pixel + 1], sample3[3 * pixel + 2]);
+    sample3[3 * pixel] = 0.0f; sample3[3 * pixel + 1] = 0.0f; sample3[3 * pixel + 2] = 0.0f;
+    if (!(well_defined(res.x) && well_defined(res.y) && well_defined(res.z))) return;
+    float4 o = accum4[pixel];
+    const int n = (int)o.w;
+    f3 cur(o.x, o.y, o.z);
+    cur = cur * (float)((double)n / (n + 1));
+    cur = cur + (float)(1.0 / (n + 1)) * res;
+    accum4[pixel] = make_float4(cur.x, cur.y, cur.z, (float)(n + 1));
+    if (aux4 && (n & 1)) {                                            // add_aux toggles per block iteration (:226-233)
+        float4 x = aux4[pixel];
+        const int na = (int)x.w;
+        f3 ca(x.x, x.y, x.z);
+        ca = ca * (float)((double)na / (na + 1));
+        ca = ca + (float)(1.0 / (na + 1)) * res;
+        aux4[pixel] = make_float4(ca.x, ca.y, ca.z, (float)(na + 1));
+    }
+}
+
 // explicit ray batch -> queue records (srx_process_rays): pixel = ray index, throughput 1
 __global__ __launch_bounds__(256) void k_pack_rays(const float* org3, const float* dir3, const unsigned long long* keys, uint32_t n, GRay* rays) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -509,6 +587,21 @@ extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int w, GRows r
     const uint32_t n = (uint32_t)(w * rows);
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, stream, c, x0, w, rows_map, j0, rows, pass_index, seed, rays, dir3, keys);
+    return hipGetLastError();
+}
+extern "C" hipError_t srx_launch_raygen_adaptive(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, AdaptiveArgs a,
+                                                 GRay* rays, uint32_t* count, hipStream_t stream) {
+    const uint32_t n = (uint32_t)(w * rows);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_raygen_adaptive, dim3((n + 255) / 256), dim3(256), 0, stream, c, x0, w, rows_map, j0, rows, a, rays, count);
+    return hipGetLastError();
+}
+extern "C" hipError_t srx_launch_accumulate_adaptive(int res_x, int x0, int w, GRows rows_map, int rows, AdaptiveArgs a, float* sample3,
+                                                     float* accum4, float* aux4, hipStream_t stream) {
+    const uint32_t n = (uint32_t)(w * rows);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_accumulate_adaptive, dim3((n + 255) / 256), dim3(256), 0, stream, res_x, x0, w, rows_map, rows, a, sample3,
+                       (float4*)accum4, (float4*)aux4);
     return hipGetLastError();
 }
 extern "C" hipError_t srx_launch_pack_rays(const float* org3, const float* dir3, const unsigned long long* keys, uint32_t n,

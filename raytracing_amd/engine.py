@@ -196,6 +196,21 @@ class RayEngine:
                                       C.c_uint32(len(org)), _p(rad), C.byref(ctr)), "srx_process_rays")
         return rad, ctr.as_dict()
 
+    def trace_visit(self, camera, rect, visit_index, seed, accum4, aux4=None, block_priority=None, ray_capacity=1 << 22,
+                    interleave=None):
+        """One visit of every 4x4 block (`RenderThread::process_iteratively`, SceneManager.h:193-237) with the
+        controller's block priorities (device tensor, None = all 1): a block takes a sample with probability
+        `priority`; a pixel's sample index is its own count so far."""
+        cam = np.ascontiguousarray(camera)
+        x0, y0, w, h = rect
+        group, part, nparts = interleave if interleave is not None else (max(1, h), 0, 1)
+        ctr = SrxCounters()
+        check(self.L.srx_trace_pass_adaptive(self.renderer(ray_capacity), _p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w),
+                                             C.c_int32(h), C.c_int32(group), C.c_int32(part), C.c_int32(nparts),
+                                             C.c_uint32(visit_index), C.c_uint64(seed), _dev_ptr(block_priority), _dev_ptr(accum4),
+                                             _dev_ptr(aux4), C.byref(ctr)), "srx_trace_pass_adaptive")
+        return ctr.as_dict()
+
     def trace_pass(self, camera, rect, pass_index, seed, accum4, aux4=None, ray_capacity=1 << 22, interleave=None):
         """One sample pass of `RenderThread::process_iteratively` (SceneManager.h:193-237) over a pixel
         rectangle; accum4/aux4 are device float4 framebuffers (torch tensors or raw addresses).
@@ -222,3 +237,62 @@ def camera_rays(camera, rect, pass_index, seed):
     check(_lib.lib().srx_camera_rays(_p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w), C.c_int32(h),
                                      C.c_uint32(pass_index), C.c_uint64(seed), _p(d), _p(k)), "srx_camera_rays")
     return d, k
+
+
+REGION_DTYPE = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("active", "<i4"), ("noise", "<f4"),
+                         ("max_noise", "<f4"), ("min_noise", "<f4"), ("avg_noise", "<f4")])
+
+
+class NoiseController:
+    """Adaptive-sampling controller: `SceneManager::analyze_noise` (SceneManager.h:526-667) and the priority half of
+    `SceneManager::balance_threads` (:668-692). Framebuffers, error map and priorities are device tensors."""
+
+    BLOCK = 4                                 # SceneManager.h:299
+
+    def __init__(self, res_x, res_y, seed=0, minimum_samples=-1, device=0):
+        self.L = _lib.lib()
+        check(self.L.srx_init(C.c_int(device)), "srx_init")
+        self.res_x, self.res_y = int(res_x), int(res_y)
+        self.h = C.c_void_p()
+        check(self.L.srx_noise_create(C.c_int32(res_x), C.c_int32(res_y), C.c_uint64(seed), C.c_int32(minimum_samples),
+                                      C.byref(self.h)), "srx_noise_create")
+
+    def close(self):
+        if self.h:
+            self.L.srx_noise_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_blocks(self):
+        return ((self.res_x + 3) // 4) * ((self.res_y + 3) // 4)
+
+    def error_map(self, accum4, aux4, err, interleave=None):
+        """Fills `err` (device, one float per pixel) for this caller's rows, 0 elsewhere; returns the minimum sample
+        count of those rows (SceneManager.h:492-501, :566-572)."""
+        group, part, nparts = interleave if interleave is not None else (self.res_y, 0, 1)
+        mn = C.c_int32(0)
+        check(self.L.srx_noise_error_map(self.h, _dev_ptr(accum4), _dev_ptr(aux4), C.c_int32(group), C.c_int32(part),
+                                         C.c_int32(nparts), _dev_ptr(err), C.byref(mn)), "srx_noise_error_map")
+        return mn.value
+
+    def analyze_noise(self, err, seen):
+        check(self.L.srx_noise_analyze(self.h, _dev_ptr(err), C.c_int32(seen)), "srx_noise_analyze")
+
+    def regions(self):
+        n = C.c_uint32(0)
+        check(self.L.srx_noise_regions(self.h, None, C.c_uint32(0), C.byref(n)), "srx_noise_regions")
+        out = np.zeros(n.value, REGION_DTYPE)
+        check(self.L.srx_noise_regions(self.h, _p(out), C.c_uint32(n.value), C.byref(n)), "srx_noise_regions")
+        return out
+
+    def balance(self, seen, block_priority):
+        """Writes the block priorities (device, `n_blocks` floats); False while `seen` < minimum_samples (all 1)."""
+        upd = C.c_int32(0)
+        check(self.L.srx_noise_priorities(self.h, C.c_int32(seen), _dev_ptr(block_priority), C.byref(upd)), "srx_noise_priorities")
+        return bool(upd.value)

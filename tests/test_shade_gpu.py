@@ -117,7 +117,8 @@ def test_small_queue_gives_same_result(loaded):
     r_small, c_small = RE2.process_ray(org, dirs, keys, generation=0, ray_capacity=4096)
     RE2.close()
     assert int(c_big["rays_processed"]) == int(c_small["rays_processed"])
-    assert int(c_small["trace_launches"]) > int(c_big["trace_launches"])
+    if desc.monte_carlo_max > 1:      # fan-out 32/8/2: 4 096 slots cannot hold a generation (the fan-out-1 box fits)
+        assert int(c_small["trace_launches"]) > int(c_big["trace_launches"])
     assert np.allclose(r_big, r_small, rtol=1e-4, atol=1e-6, equal_nan=True)
 
 
