@@ -45,19 +45,24 @@ def parse():
     ap.add_argument("--cpu-sample", type=str, default="1920x1080", help="centre crop of the frame timed on the host cores")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20241111)
+    ap.add_argument("--scene", default="atrium", choices=["atrium", "interior", "diffuse_box"],
+                    help="atrium = the headline workload (configs[1]); interior = configs[2] (C3), diffuse_box = configs[4] (C5)")
+    ap.add_argument("--adaptive", type=int, default=0, metavar="MIN_SAMPLES",
+                    help="not the headline run: after the timed steps, run the adaptive-sampling loop (controller's minimum_samples = "
+                         "MIN_SAMPLES, analysis every 4 visits) and report it under config.adaptive")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: exchange staged through the host)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
-def measured_traffic(tris, res):
+def measured_traffic(tris, res, scene="atrium"):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc needs its own
     runs, so it cannot be collected inside the timed run); None when the workload differs from the profiled one."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
             t = json.load(fh)
         w = t["workload"]
-        if w["tris"] == tris and w["res"] == res and w["max_generations"] == 8:
+        if scene == "atrium" and w["tris"] == tris and w["res"] == res and w["max_generations"] == 8:
             return float(t["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
@@ -87,6 +92,41 @@ def cpu_baseline(desc, cam, crop, seed, threads):
     }
 
 
+def adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, barrier):
+    """SceneManager's mode-1 loop (SceneManager.h:970-993) on the GPU: visits of every 4x4 block with the
+    controller's priorities, analyze_noise + balance_threads every 4 visits (the reference: every 2 s)."""
+    import torch
+    from raytracing_amd import engine, tiles
+    NC = engine.NoiseController(W, H, seed=args.seed, minimum_samples=args.adaptive)
+    err = torch.zeros(W * H, dtype=torch.float32, device="cuda")
+    prio = torch.ones(NC.n_blocks, dtype=torch.float32, device="cuda")
+    visit = args.warmup + args.steps
+    log, analyses_ms, visits_ms, rays = [], 0.0, 0.0, 0
+    while visit < args.warmup + args.steps + 4 * 12 + args.adaptive:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            c = RE.trace_visit(cam, rect, visit, args.seed, accum, aux, block_priority=prio, ray_capacity=args.ray_capacity, interleave=share)
+            rays += c["rays_processed"]
+            visit += 1
+        barrier()
+        t1 = time.perf_counter()
+        seen = tiles.allreduce_error_map(err, NC.error_map(accum, aux, err, interleave=share))
+        NC.analyze_noise(err, seen)
+        NC.balance(seen, prio)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        visits_ms += (t1 - t0) * 1e3
+        analyses_ms += (t2 - t1) * 1e3
+        R = NC.regions()
+        lum = tiles.luminance(accum[:, :3])
+        log.append({"negative_luminance_pixels": int((lum < 0).sum()), "nan_error_pixels": int(torch.isnan(err).sum()),"visit": visit, "min_samples": seen, "regions": int(len(R)), "active_regions": int(R["active"].sum()),
+                    "mean_priority": float(prio.mean()), "visits_ms": (t1 - t0) * 1e3, "analysis_ms": (t2 - t1) * 1e3})
+    NC.close()
+    return {"minimum_samples": args.adaptive, "visits_ms": visits_ms, "analyses_ms": analyses_ms, "rays_this_rank": rays,
+            "rounds": log[:2] + log[-3:]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -111,7 +151,12 @@ def main():
     from raytracing_amd import engine, scenes
 
     W, H = (int(v) for v in args.res.split("x"))
-    desc = scenes.atrium(args.tris, res=(W, H), subdiv=8, max_generations=8)
+    if args.scene == "atrium":
+        desc = scenes.atrium(args.tris, res=(W, H), subdiv=8, max_generations=8)
+    elif args.scene == "interior":
+        desc = scenes.interior(args.tris, res=(W, H), subdiv=8)
+    else:
+        desc = scenes.diffuse_box(args.tris, res=(W, H), subdiv=8)
     cam = desc.camera
     t0 = time.perf_counter()
     PS = engine.package(desc)
@@ -150,6 +195,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    adaptive = None
+    if args.adaptive > 0:
+        adaptive = adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, barrier)
+
     keys = ["rays_processed", "shadows_cast", "nodes", "packets", "shadow_nodes", "shadow_packets", "hits",
             "trace_launches", "shadow_launches", "shade_launches"]
     vals = torch.tensor([float(tot[k]) for k in keys] + [tot["trace_ms"], tot["shadow_ms"], tot["shade_ms"], dt],
@@ -185,8 +234,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"procedural Sponza-class atrium, {args.tris} tris, {W}x{H}, 1 spp per step, max_generations 8, "
-                            f"monte_carlo_max 32 ({'BASELINE.json configs[1]' if (args.tris, args.res) == (262144, '1920x1080') else 'configs[1] scaled'})",
+                "workload": (f"procedural Sponza-class atrium, {args.tris} tris, {W}x{H}, 1 spp per step, max_generations 8, "
+                             f"monte_carlo_max 32 ({'BASELINE.json configs[1]' if (args.tris, args.res) == (262144, '1920x1080') else 'configs[1] scaled'})")
+                            if args.scene == "atrium" else
+                            f"{desc.name}, {len(desc.tris)} tris, {W}x{H}, 1 spp per step, max_generations {desc.max_generations}, "
+                            f"monte_carlo_max {desc.monte_carlo_max} (not the headline workload)",
                 "parallelism": f"interleaved tile rows x{world}, scene replicated",
                 "rays_per_step": rays / args.steps,
                 "shadow_rays_per_step": agg["shadows_cast"] / args.steps,
@@ -200,7 +252,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.tris, args.res) if world == 1 else None,
+                "traffic": measured_traffic(args.tris, args.res, args.scene) if world == 1 else None,
                 "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, bytes per launch)",
                 "launches": int(launches),
                 "avg_launch_ms": trace_ms / launches,
@@ -211,6 +263,8 @@ def main():
                 "kernel_ms": {"trace": trace_ms, "shadow": shadow_ms, "shade": shade_ms, "wall": dt * 1e3},
             },
         }
+        if adaptive is not None:
+            out["config"]["adaptive"] = adaptive
         if not args.no_cpu_baseline and world == 1:
             threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             cw, ch = (int(v) for v in args.cpu_sample.split("x"))

@@ -207,8 +207,8 @@ int srx_noise_priorities(srx_noise* c, int32_t seen, float* d_block_priority, in
 
 /* One VISIT of every 4x4 block of this caller's rows (RenderThread::process_iteratively, SceneManager.h:193-237):
  * a block takes floor(p) + [u < frac(p)] samples (0 or 1; p <= 1 by construction) with u keyed by (seed, visit_index,
- * block); a pixel's sample index is its own count so far (block->iterations_done) and the aux buffer takes the odd
- * ones (:226-233). d_block_priority NULL = all 1. With all priorities 1 and equal counts this is srx_trace_pass. */
+ * block); a pixel's stratum and running-mean weight come from its own count so far (block->iterations_done), its
+ * random stream from (seed, visit_index, pixel), and the aux buffer takes the odd counts (:226-233). d_block_priority NULL = all 1. With all priorities 1 and equal counts this is srx_trace_pass. */
 int srx_trace_pass_adaptive(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
                             int32_t group_rows, int32_t part, int32_t nparts, uint32_t visit_index, uint64_t seed,
                             const float* d_block_priority, float* d_accum4, float* d_aux4, srx_counters* counters);

@@ -368,8 +368,9 @@ int32_t sro_noise_block_fires(float priority, uint64_t seed, uint32_t visit_inde
 }
 
 // One visit of every 4x4 block of the rectangle (RenderThread::process_iteratively, SceneManager.h:193-237) with
-// per-block priorities (NULL = all 1): a block that fires takes one keyed sample per pixel; the sample index of a
-// pixel is its own count so far (block->iterations_done), the aux buffer takes the odd ones (:226-233).
+// per-block priorities (NULL = all 1): a block that fires takes one keyed sample per pixel; the stratum and the
+// running-mean weight come from the pixel's own count so far (block->iterations_done), the aux buffer takes the odd
+// ones (:226-233).
 int sro_render_pass_adaptive(void* hv, const sro_camera_in* c, int32_t x0, int32_t y0, int32_t w, int32_t hgt,
                              uint32_t visit_index, uint64_t seed, const float* block_priority, int32_t threads,
                              float* accum4, float* aux4, uint64_t* stats8) {
@@ -396,7 +397,8 @@ int sro_render_pass_adaptive(void* hv, const sro_camera_in* c, int32_t x0, int32
                     ray.position = cam.position;
                     ray.generation = 0;
                     KeyedGen g;
-                    g.s = KeyedGen::primary_key(seed, (uint64_t)n * npix + (uint64_t)y * c->res_x + x);
+                    // stratum from the pixel's count; stream keyed by the visit (a rejected sample is not repeated)
+                    g.s = KeyedGen::primary_key(seed, (uint64_t)visit_index * npix + (uint64_t)y * c->res_x + x);
                     ray.slope = cam.random_slope_at(x, y, n % spp, g);
                     ray.key = g.s;
                     XYZ res = RE.process_ray(st[tid], ray);

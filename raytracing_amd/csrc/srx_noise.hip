@@ -8,8 +8,8 @@
 //           k_paint_regions, k_block_priority   noise map (:670-676) and the 4x4-block priorities (:679-692)
 //   host    the region list and the split search (:582-665): a few hundred scalar steps per region whose ORDER is
 //           load-bearing (the list order feeds the running-min average of the next analysis, :535-547), driven by
-//           the measured sums; every region that exists when the analysis starts is measured in one launch, a split
-//           measures its two halves in another.
+//           the measured sums; every region that exists when the analysis starts is measured in one launch, the two
+//           halves of a split are summed on the host in the same order (no launch per split).
 // Differences from the reference (shared with the CPU oracle): the tie-break draw of :639 is keyed by the region's
 // rectangle and the analysis index; a split at offset 0 is refused (the reference would loop for ever on it).
 #include "srx_host.h"
@@ -275,12 +275,44 @@ extern "C" int srx_noise_analyze(srx_noise* c, const float* d_err, int32_t seen)
         for (size_t i = 0; i < R.size(); i++) rects[i] = Rect{R[i].x0, R[i].y0, R[i].x1, R[i].y1};
         if (measure(c, d_err, rects, stats)) return 1;
     }
-    auto split_measure = [&](size_t left, size_t right) -> int {         // the two halves of a split
-        std::vector<Rect> rects = {Rect{R[left].x0, R[left].y0, R[left].x1, R[left].y1}, Rect{R[right].x0, R[right].y0, R[right].x1, R[right].y1}};
-        std::vector<Stats> two;
-        if (measure(c, d_err, rects, two)) return 1;
-        stats[left] = std::move(two[0]);
-        stats.push_back(std::move(two[1]));
+    // The two halves of a split are summed on the host from a copy of the map (fetched at the first split): same
+    // accumulation order as k_region_stats, bit for bit, without a launch and three copies per split (the first
+    // analysis after minimum_samples makes thousands of splits).
+    std::vector<float> h_err;
+    auto host_stats = [&](const srx_noise_region& NR, Stats& st) {
+        const int dX = NR.x1 - NR.x0, dY = NR.y1 - NR.y0;
+        st.col.assign((size_t)std::max(dX, 0), 0.0f); st.row.assign((size_t)std::max(dY, 0), 0.0f); st.total = 0;
+        if (dX <= 0 || dY <= 0) return;
+        const double count = (double)(dX * dY);
+        const float col_scalar = (float)(1.0 / dY), row_scalar = (float)(1.0 / dX);
+        double total = 0.0;
+        for (int x = NR.x0; x < NR.x1; x++) {
+            float acc = 0.0f;
+            double tot = 0.0;
+            for (int y = NR.y0; y < NR.y1; y++) {
+                const float e = h_err[(size_t)y * c->res_x + x];
+                acc += e * col_scalar;
+                tot += (double)e / count;
+            }
+            st.col[x - NR.x0] = acc;
+            total += tot;
+        }
+        for (int y = NR.y0; y < NR.y1; y++) {
+            float acc = 0.0f;
+            const float* row = &h_err[(size_t)y * c->res_x];
+            for (int x = NR.x0; x < NR.x1; x++) acc += row[x] * row_scalar;
+            st.row[y - NR.y0] = acc;
+        }
+        st.total = total;
+    };
+    auto split_measure = [&](size_t left, size_t right) -> int {
+        if (h_err.empty()) {
+            h_err.resize((size_t)c->res_x * c->res_y);
+            SRX_HIP(hipMemcpy(h_err.data(), d_err, h_err.size() * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        host_stats(R[left], stats[left]);
+        stats.emplace_back();
+        host_stats(R[right], stats.back());
         return 0;
     };
     for (int i = 0; i < (int)R.size(); i++) {                            // :552-666

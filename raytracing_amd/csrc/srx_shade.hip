@@ -496,7 +496,9 @@ __global__ __launch_bounds__(256) void k_raygen_adaptive(GCamera c, int x0, int 
     const uint32_t slot = s_base + before + (uint32_t)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
     const uint64_t npix = (uint64_t)c.res_x * c.res_y;
     KeyedGen g;
-    g.s = KeyedGen::primary_key(a.seed, (uint64_t)n * npix + pixel);
+    // stratum from the pixel's own count (iterations_done % samples_per_pixel, :212); the stream is keyed by the visit
+    // so that a rejected (non-finite) sample is followed by a different draw, like the reference's redraw (:220-223)
+    g.s = KeyedGen::primary_key(a.seed, (uint64_t)a.visit_index * npix + pixel);
     const f3 d = camera_slope(c, px, py, n, g);
     GRay r;
     r.ox = c.pos[0]; r.oy = c.pos[1]; r.oz = c.pos[2];

@@ -112,6 +112,20 @@ def allreduce_noise_stats(sums: torch.Tensor, min_samples: torch.Tensor):
     return sums, min_samples
 
 
+def allreduce_error_map(err: torch.Tensor, min_samples: int):
+    """Completes the per-pixel error map of the adaptive-sampling controller: every rank filled its own rows and
+    left the others 0 (`srx_noise_error_map`), so all-reduce(sum) yields the whole map on every rank; the minimum
+    sample count is all-reduce(min) (`gather_thread_stats`, SceneManager.h:492-501). Returns the global minimum."""
+    if not _is_dist():
+        return int(min_samples)
+    _host_staged(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM), err)
+    mn = torch.tensor([int(min_samples)], dtype=torch.int64)
+    if dist.get_backend() != "gloo":
+        mn = mn.to(err.device)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    return int(mn.item())
+
+
 def luminance(rgb: torch.Tensor):
     """`ImageProcessing::luminance` weights (ImageProcessing.h:115-118)."""
     return 0.2126 * rgb[..., 0] + 0.7152 * rgb[..., 1] + 0.0722 * rgb[..., 2]

@@ -98,3 +98,32 @@ def test_interleaved_rows_partition_the_frame():
                 rows = tiles.interleaved_rows(r, world, H).tolist()
                 g = tiles.TILE
                 assert rows == [((j // g) * world + r) * g + j % g for j in range(len(rows))]
+
+
+def _worker_errmap(rank, world, port, H, W, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracing_amd import tiles
+    full = torch.rand(H, W, generator=torch.Generator().manual_seed(3))
+    rows = tiles.interleaved_rows(rank, world, H)
+    mine = torch.zeros(H, W)
+    mine[rows] = full[rows]                      # what srx_noise_error_map leaves on this rank
+    mn = tiles.allreduce_error_map(mine.view(-1), 40 + rank)
+    q.put((rank, bool(torch.equal(mine, full)), mn))
+    dist.destroy_process_group()
+
+
+def test_error_map_allreduce_world2():
+    H, W, world, port = 22, 7, 2, 33500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_errmap, args=(r, world, port, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, mn in res:
+        assert ok and mn == 40
