@@ -10,6 +10,14 @@
 //
 // srx_build_tables replaces VecLib::prep's arccos table (VecLib.cpp:391-398) and PDF::prep (PDF.h:83-123).
 #include "../../include/srx.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -70,10 +78,32 @@ float evaluate(Split& s) {          // BVH.h:676-694 with PENALIZE_UNFILLED_LEAF
     return h;
 }
 
+// Node arena that can grow while other threads read nodes they already know: fixed-size chunks, the chunk table is
+// sized up front (a binary tree over n triangles has < 2n nodes), a node index is handed out only after its chunk
+// exists, and indices reach other threads through the (mutex-protected) work queue.
+struct NodePool {
+    enum { SHIFT = 14, CHUNK = 1 << SHIFT };
+    std::vector<std::unique_ptr<BNode[]>> chunks;
+    std::atomic<int> next{0};
+    std::mutex grow;
+    explicit NodePool(size_t max_nodes) : chunks(max_nodes / CHUNK + 2) {}
+    int alloc() {
+        const int i = next.fetch_add(1);
+        const size_t c = (size_t)i >> SHIFT;
+        if (!chunks[c]) {
+            std::lock_guard<std::mutex> lk(grow);
+            if (!chunks[c]) chunks[c].reset(new BNode[CHUNK]);
+        }
+        return i;
+    }
+    BNode& operator[](int i) { return chunks[(size_t)i >> SHIFT][i & (CHUNK - 1)]; }
+    int size() const { return next.load(); }
+};
+
 struct Builder {
     const std::vector<HTri>& T;
-    std::deque<BNode> pool;
-    explicit Builder(const std::vector<HTri>& t) : T(t) {}
+    NodePool pool;
+    explicit Builder(const std::vector<HTri>& t) : T(t), pool(2 * t.size() + 2) {}
 
     void stats(const std::vector<uint32_t>& geo, Split& s) {      // get_stats BVH.h:659-675
         s.p.count = s.n.count = 0;
@@ -87,13 +117,21 @@ struct Builder {
         }
     }
 
-    struct Rec { v3 mid, mx, mn, rmx, rmn; };                      // relevant_value BVH.h:331-345
+    // relevant_value BVH.h:331-345. The reference std::sorts these records three times in a row (one axis after the
+    // other, each sort starting from the order the previous one left, which decides how ties fall). std::sort's moves
+    // depend on the comparison results only, so sorting 8-byte (key, position) proxies with the same comparison and
+    // then gathering the records gives the same order at a fraction of the memory traffic.
+    struct Rec { v3 mid, mx, mn; };
+    struct Suffix { v3 rmx, rmn; };
+    struct Key { float k; uint32_t pos; };
     Split probe(const std::vector<uint32_t>& geo) {               // BVH.h:581-653
-        std::vector<Rec> sorted(geo.size());
-        for (size_t i = 0; i < geo.size(); i++) {
+        const int N = (int)geo.size();
+        std::vector<Rec> sorted(N), gathered(N);
+        std::vector<Suffix> suffix(N);
+        std::vector<Key> keys(N);
+        for (int i = 0; i < N; i++) {
             const HTri& t = T[geo[i]];
             vset(sorted[i].mid, t.mid); vset(sorted[i].mx, t.bmax); vset(sorted[i].mn, t.bmin);
-            vfill(sorted[i].rmx, 0); vfill(sorted[i].rmn, 0);
         }
         Split op;
         vfill(op.p.mn, 99999999999.f); vfill(op.p.mx, 0); op.p.count = 0;   // Stats defaults :259-262
@@ -101,16 +139,20 @@ struct Builder {
         vfill(op.placement, 0); op.facing = 0; op.score = 0;
         Split best = op;
         best.score = 999999999999999999999999.0f;
-        const int N = (int)geo.size();
         for (int ax = 0; ax < 3; ax++) {
             op.facing = ax;
-            std::sort(sorted.begin(), sorted.end(), [ax](const Rec& a, const Rec& b) { return a.mid[ax] < b.mid[ax]; });
+            for (int i = 0; i < N; i++) { keys[i].k = sorted[i].mid[ax]; keys[i].pos = (uint32_t)i; }
+            // (a radix sort is no option: float centroids collide at scale, ~4 000 equal pairs per million, and the order
+            // of equal keys is whatever std::sort makes of the incoming sequence)
+            std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.k < b.k; });
+            for (int i = 0; i < N; i++) gathered[i] = sorted[keys[i].pos];
+            sorted.swap(gathered);
             v3 lmn, lmx, rmn, rmx;
             vset(lmn, sorted.front().mn); vset(lmx, sorted.front().mx);
             vset(rmn, sorted.back().mn);  vset(rmx, sorted.back().mx);
             for (int j = N - 1; j >= 0; j--) {
                 vmin(rmn, rmn, sorted[j].mn); vmax(rmx, rmx, sorted[j].mx);
-                vset(sorted[j].rmn, rmn); vset(sorted[j].rmx, rmx);
+                vset(suffix[j].rmn, rmn); vset(suffix[j].rmx, rmx);
             }
             vfill(op.n.mn, 0); vfill(op.n.mx, 0); op.n.count = 0;
             vset(op.p.mn, rmn); vset(op.p.mx, rmx); op.p.count = N;
@@ -122,7 +164,7 @@ struct Builder {
                 vmin(lmn, lmn, v.mn); vmax(lmx, lmx, v.mx);
                 count++;
                 vset(op.n.mn, lmn); vset(op.n.mx, lmx); op.n.count = count;
-                vset(op.p.mn, v.rmn); vset(op.p.mx, v.rmx); op.p.count = N - count;
+                vset(op.p.mn, suffix[j].rmn); vset(op.p.mx, suffix[j].rmx); op.p.count = N - count;
                 vset(op.placement, v.mid);
                 evaluate(op);
                 if (op.score < best.score) best = op;
@@ -132,56 +174,104 @@ struct Builder {
     }
 
     int make_leaf(const std::vector<uint32_t>& ids) {             // BVH(vector<Tri*>*) BVH.h:27-34 — quirk Q1
-        pool.emplace_back();
-        BNode& b = pool.back();
+        const int me = pool.alloc();
+        BNode& b = pool[me];
         b.elements = ids;
         for (uint32_t id : ids) { vmax(b.mx, b.mx, T[id].bmax); vmin(b.mn, b.mn, T[id].bmin); }
-        return (int)pool.size() - 1;
+        return me;
     }
 
-    int construct(std::vector<uint32_t> all) {                    // BVH.h:98-180
-        pool.emplace_back();
-        std::deque<std::pair<int, std::vector<uint32_t>>> work;
-        work.emplace_back(0, std::move(all));
-        while (!work.empty()) {
-            const int target = work.front().first;
-            std::vector<uint32_t> geo = std::move(work.front().second);
-            work.pop_front();
-            v3 bmx, bmn;                                           // getBounds :308-315
-            vfill(bmx, -99999999999999.f); vfill(bmn, 99999999999999.f);
-            for (uint32_t id : geo) {
-                vmax(bmx, bmx, T[id].bmax); vmin(bmn, bmn, T[id].bmax);
-                vmax(bmx, bmx, T[id].bmin); vmin(bmn, bmn, T[id].bmin);
-            }
-            vset(pool[target].mx, bmx); vset(pool[target].mn, bmn);
-            v3 ext = {bmx[0] - bmn[0], bmx[1] - bmn[1], bmx[2] - bmn[2]};
-            int axis = 0;
-            if (ext[1] > ext[0]) axis = 1;
-            if (ext[2] > ext[axis]) axis = 2;
-            const float splitPos = bmn[axis] + ext[axis] * 0.5f;
-            Split split;
-            vfill(split.placement, splitPos); split.facing = axis;
-            stats(geo, split); evaluate(split);
-            Split pr = probe(geo);
-            stats(geo, pr); evaluate(pr);
-            if (pr.score < split.score) split = pr;
-            std::vector<uint32_t> pg, ng;                          // bin :316-330
-            for (uint32_t id : geo) {
-                if (T[id].mid[split.facing] > split.placement[split.facing]) pg.push_back(id);
-                else ng.push_back(id);
-            }
-            if (pg.empty() || ng.empty()) {                        // :145-149 — keeps the tight bounds
-                pool[target].elements = geo;
-                continue;
-            }
-            int c1, c2;
-            if (pg.size() <= 8) c1 = make_leaf(pg);
-            else { pool.emplace_back(); c1 = (int)pool.size() - 1; work.emplace_back(c1, std::move(pg)); }
-            if (ng.size() <= 8) c2 = make_leaf(ng);
-            else { pool.emplace_back(); c2 = (int)pool.size() - 1; work.emplace_back(c2, std::move(ng)); }
-            pool[target].c1 = c1; pool[target].c2 = c2;
+    // One step of BVH::construct (BVH.h:98-180) for node `target`; children that need splitting come back in `more`.
+    // A node's split depends on its own triangle list only, so subtrees can be built in any order or in parallel:
+    // the tree (and with it every array of the package) is the same.
+    typedef std::pair<int, std::vector<uint32_t>> Work;
+    void split_node(int target, std::vector<uint32_t>& geo, std::vector<Work>& more) {
+        v3 bmx, bmn;                                               // getBounds :308-315
+        vfill(bmx, -99999999999999.f); vfill(bmn, 99999999999999.f);
+        for (uint32_t id : geo) {
+            vmax(bmx, bmx, T[id].bmax); vmin(bmn, bmn, T[id].bmax);
+            vmax(bmx, bmx, T[id].bmin); vmin(bmn, bmn, T[id].bmin);
         }
-        return 0;
+        vset(pool[target].mx, bmx); vset(pool[target].mn, bmn);
+        v3 ext = {bmx[0] - bmn[0], bmx[1] - bmn[1], bmx[2] - bmn[2]};
+        int axis = 0;
+        if (ext[1] > ext[0]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        const float splitPos = bmn[axis] + ext[axis] * 0.5f;
+        Split split;
+        vfill(split.placement, splitPos); split.facing = axis;
+        stats(geo, split); evaluate(split);
+        Split pr = probe(geo);
+        stats(geo, pr); evaluate(pr);
+        if (pr.score < split.score) split = pr;
+        std::vector<uint32_t> pg, ng;                              // bin :316-330
+        for (uint32_t id : geo) {
+            if (T[id].mid[split.facing] > split.placement[split.facing]) pg.push_back(id);
+            else ng.push_back(id);
+        }
+        if (pg.empty() || ng.empty()) {                            // :145-149 — keeps the tight bounds
+            pool[target].elements = geo;
+            return;
+        }
+        int c1, c2;
+        if (pg.size() <= 8) c1 = make_leaf(pg);
+        else { c1 = pool.alloc(); more.emplace_back(c1, std::move(pg)); }
+        if (ng.size() <= 8) c2 = make_leaf(ng);
+        else { c2 = pool.alloc(); more.emplace_back(c2, std::move(ng)); }
+        pool[target].c1 = c1; pool[target].c2 = c2;
+    }
+
+    int construct(std::vector<uint32_t> all, int threads) {       // BVH.h:98-180
+        const int root = pool.alloc();
+        std::deque<Work> work;
+        work.emplace_back(root, std::move(all));
+        if (threads <= 1) {
+            std::vector<Work> more;
+            while (!work.empty()) {
+                Work w = std::move(work.front());
+                work.pop_front();
+                more.clear();
+                split_node(w.first, w.second, more);
+                for (Work& m : more) work.push_back(std::move(m));
+            }
+            return root;
+        }
+        std::mutex mu;
+        std::condition_variable cv;
+        int busy = 0;                                              // items taken and not finished yet
+        std::string failure;
+        auto worker = [&]() {
+            std::vector<Work> more;
+            for (;;) {
+                Work w;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !work.empty() || busy == 0 || !failure.empty(); });
+                    if (!failure.empty() || work.empty()) return;  // empty and nobody busy: the tree is complete
+                    w = std::move(work.front());
+                    work.pop_front();
+                    busy++;
+                }
+                more.clear();
+                try {
+                    split_node(w.first, w.second, more);
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    failure = e.what();
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    for (Work& m : more) work.push_back(std::move(m));
+                    busy--;
+                }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> crew;
+        for (int t = 0; t < threads; t++) crew.emplace_back(worker);
+        for (std::thread& t : crew) t.join();
+        if (!failure.empty()) throw std::runtime_error(failure);
+        return root;
     }
 
     int count(int id) {                                            // BVH::count :217-229 (cache starts at -1)
@@ -268,7 +358,15 @@ extern "C" int srx_package_create(const srx_tri* in, uint32_t n, srx_package** o
         Builder B(T);
         std::vector<uint32_t> all(n);
         for (uint32_t i = 0; i < n; i++) all[i] = i;
-        B.construct(std::move(all));
+        // Subtrees are built by a small crew of threads (SRX_BUILD_THREADS, default min(cores, 16)); the result does
+        // not depend on the thread count (tested byte for byte).
+        int threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("SRX_BUILD_THREADS")) threads = std::max(1, std::atoi(e));
+        if (n < 4096) threads = 1;
+        const bool timing = std::getenv("SRX_BUILD_TIMING") != nullptr;
+        const auto t_begin = std::chrono::steady_clock::now();
+        B.construct(std::move(all), threads);
+        const auto t_tree = std::chrono::steady_clock::now();
 
         // ---- 8-wide collapse, level order (BVH.h:1008-1077)
         srx_package* P = new srx_package();
@@ -356,6 +454,11 @@ extern "C" int srx_package_create(const srx_tri* in, uint32_t n, srx_package** o
         P->n_nodes = (uint32_t)node_recs.size();
         P->nodes.resize((size_t)P->n_nodes * 288);
         for (size_t i = 0; i < node_recs.size(); i++) std::memcpy(P->nodes.data() + i * 288, node_recs[i].data(), 288);
+        if (timing) {
+            const auto t_end = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "srx_package_create: %u tris, %d threads: tree %.2f s, collapse + packets %.2f s\n", n, threads,
+                         std::chrono::duration<double>(t_tree - t_begin).count(), std::chrono::duration<double>(t_end - t_tree).count());
+        }
         *out = P;
         return 0;
     } catch (const std::exception& e) {
