@@ -370,6 +370,8 @@ extern "C" int srx_package_create(const srx_tri* in, uint32_t n, srx_package** o
 
         // ---- 8-wide collapse, level order (BVH.h:1008-1077)
         srx_package* P = new srx_package();
+        P->tris.reserve((size_t)n * 196);
+        P->packets.reserve(((size_t)n / 6 + 16) * 448);
         struct Item { int node, parent, slot; };
         std::vector<Item> cur{{0, -1, -1}}, next;
         std::vector<std::vector<uint8_t>> node_recs;

@@ -103,3 +103,86 @@ def test_empty_batch(loaded):
     name, desc, RE, S = loaded
     g, gc = RE.execute_ray_cast(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
     assert len(g) == 0 and int(gc[0]) == 0
+
+
+def test_axis_aligned_zero_and_nonfinite_rays(loaded):
+    """Directions with zero components give +-inf / NaN in 1/d and -o/d (Core.h:53-54 does not guard them): a wave
+    holding such a ray leaves the hardware min/max path for the x86 second-operand-on-NaN form. Mixed with ordinary
+    rays so both forms run in the same launch; results and test counts must still be the oracle's."""
+    name, desc, RE, S = loaded
+    org, dirs = random_rays(4096, seed=41, extent=0.9 if name == "cornell" else 3.0)
+    special = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0], [1, 1, 0],
+                        [0, -1, 1], [1e-30, 1, 0], [np.inf, 1, 0], [np.nan, 0, 1], [1e30, -1e30, 1e30]], np.float32)
+    idx = np.arange(0, len(dirs), 37)
+    dirs[idx] = special[np.arange(len(idx)) % len(special)]
+    org[idx[::3]] = 0.0                                   # rays from the origin: -0/d
+    org[idx[1::11], 0] = np.nan
+    with np.errstate(all="ignore"):
+        g, gc = RE.execute_ray_cast(org, dirs)
+        c, cc = S.cast_closest(org, dirs)
+    _assert_hits_equal(g, c)
+    assert int(gc[0]) == int(cc[0]) and int(gc[1]) == int(cc[1])
+
+
+def test_multi_packet_leaves_and_ties(tables):
+    """Coincident triangles cannot be split (BVH.h:145-149): one leaf of 40 triangles = 5 packets walked like the
+    reference's inner loop (Core.h:179); equal t in several lanes and packets: the first one seen wins (:231-239)."""
+    from oracle import sro
+    from raytracing_amd import engine, scenes
+    desc = scenes.soup(600, seed=8, extent=2.0)
+    tris = desc.tris.copy()
+    tris[100:140] = tris[100]                              # 40 copies of one triangle
+    tris[300:309] = tris[300]                              # 9 copies: 2 packets
+    desc.tris = tris
+    PS = engine.package(desc, tables=tables)
+    n = PS.avx_bvh
+    leaf = n[:, 192:224].copy().view(np.uint32)
+    assert leaf.max() >= 5
+    RE = engine.RayEngine(0)
+    RE.load_scene(PS)
+    S = sro.OracleScene(desc, tables=tables)
+    rng = np.random.default_rng(3)
+    targets = np.concatenate([tris["p"][100].reshape(3, 3).mean(0, keepdims=True).repeat(3000, 0),
+                              tris["p"][300].reshape(3, 3).mean(0, keepdims=True).repeat(3000, 0)]).astype(np.float32)
+    org = (targets + rng.normal(size=targets.shape).astype(np.float32) * 1.5).astype(np.float32)
+    dirs = (targets + rng.normal(size=targets.shape).astype(np.float32) * 0.02 - org).astype(np.float32)
+    g, gc = RE.execute_ray_cast(org, dirs)
+    c, cc = S.cast_closest(org, dirs)
+    _assert_hits_equal(g, c)
+    assert int(gc[0]) == int(cc[0]) and int(gc[1]) == int(cc[1])
+    hit_dup = np.isin(PS.tri_data[:, 0:36].view(np.float32).reshape(-1, 9)[g["tri_index"][g["material"] != 0xFFFFFFFF]][:, :3],
+                      tris["p"][100][:3]).all(1).sum()
+    assert hit_dup > 100
+    lit_g = RE.execute_lighting_cast(org, np.array([0.1, 0.2, 0.97], np.float32))
+    lit_c = S.cast_shadow(org, np.tile(np.array([0.1, 0.2, 0.97], np.float32), (len(org), 1)))
+    assert np.array_equal(lit_g, lit_c)
+    RE.close()
+
+
+def test_million_triangle_scene(tables):
+    """Scale case (towards BASELINE configs[3]): 1 M triangles, 75 MB of nodes + packets — past the L2s, byte offsets
+    beyond 2^26; the packages of the threaded product builder and of the oracle must be identical, then the casts."""
+    from oracle import sro
+    from raytracing_amd import engine, scenes
+    desc = scenes.atrium(1_000_000, res=(256, 144), subdiv=2, tex_size=64)
+    PS = engine.package(desc, tables=tables)
+    S = sro.OracleScene(desc, tables=tables)
+    on, op, ot = S.packaged()
+    assert np.array_equal(on, PS.avx_bvh) and np.array_equal(op, PS.avx_tri_data) and np.array_equal(ot, PS.tri_data)
+    RE = engine.RayEngine(0)
+    RE.load_scene(PS)
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    dirs, _ = sro.camera_rays_keyed(cam, (0, 0, w, h), 0, 7)
+    org = np.tile(np.asarray(cam["position"], np.float32), (len(dirs), 1))
+    g, gc, adv = RE.execute_ray_cast(org, dirs, want_advanced=True)
+    c, cc = S.cast_closest(org, dirs)
+    _assert_hits_equal(g, c)
+    assert int(gc[0]) == int(cc[0]) and int(gc[1]) == int(cc[1])
+    sel = g["material"] != 0xFFFFFFFF
+    _, d2 = random_rays(int(sel.sum()), seed=2)
+    g2, gc2 = RE.execute_ray_cast(adv[sel], d2)
+    c2, cc2 = S.cast_closest(adv[sel], d2)
+    _assert_hits_equal(g2, c2)
+    assert int(gc2[0]) == int(cc2[0]) and int(gc2[1]) == int(cc2[1])
+    RE.close()
