@@ -21,8 +21,7 @@
 #endif
 #define SRX_OCTETS_PER_BLOCK (SRX_TRACE_THREADS / 8)
 // Rays per octet: an octet works through K rays one after the other, so a wave carries 8 K rays and ends when its
-// slowest OCTET ends: the sum of K ray lengths varies less than one length (a wave of 8 single rays spends 42 % of
-// its octet-trips on rays that are already done). All K set-ups (the IEEE divides of Core.h:53-54) are computed up
+// slowest OCTET ends: the sum of K ray lengths varies less than one length (K = 4 saves 7 % of the wave-trips). All K set-ups (the IEEE divides of Core.h:53-54) are computed up
 // front, one ray per lane, and parked in LDS; switching rays costs three LDS reads.
 // Measured (bench workload): K = 1 / 2 / 3 / 4 / 5 / 6 / 8 -> 1002 / 1007 / 1031 / 1041 / 1044 / 944 / 950 Mrays/s (the
 // shadow kernel gains 12 %, the closest-hit kernel nothing; from K = 6 the LDS footprint costs a wave per SIMD).
