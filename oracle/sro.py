@@ -121,7 +121,7 @@ class OracleScene:
         n = len(org)
         out = np.zeros(n, HIT_DTYPE)
         adv = np.zeros((n, 3), np.float32) if want_advanced else None
-        ctr = np.zeros(3, np.uint64)
+        ctr = np.zeros(4, np.uint64)
         self._chk(self.L.sro_cast_closest(self.h, _p(org), _p(dirs), C.c_uint32(n), _p(out), _p(adv), _p(ctr)))
         return (out, ctr, adv) if want_advanced else (out, ctr)
 
@@ -137,7 +137,7 @@ class OracleScene:
         dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
         keys = np.ascontiguousarray(keys, np.uint64)
         rad = np.zeros((len(org), 3), np.float32)
-        st = np.zeros(8, np.uint64)
+        st = np.zeros(10, np.uint64)
         self._chk(self.L.sro_process_rays_keyed(self.h, _p(org), _p(dirs), _p(keys), C.c_int32(generation),
                                                 C.c_uint32(len(org)), _p(rad), _p(st)))
         return rad, st
@@ -145,7 +145,7 @@ class OracleScene:
     def render_pass(self, camera, rect, pass_index, seed, accum4, aux4=None, mode=0, threads=1):
         cam = np.ascontiguousarray(camera)
         x0, y0, w, h = rect
-        st = np.zeros(8, np.uint64)
+        st = np.zeros(10, np.uint64)
         self._chk(self.L.sro_render_pass(self.h, _p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w), C.c_int32(h),
                                          C.c_uint32(pass_index), C.c_uint64(seed), C.c_int32(mode), C.c_int32(threads),
                                          _p(accum4), _p(aux4), _p(st)))
@@ -156,7 +156,7 @@ def _render_pass_adaptive(self, camera, rect, visit_index, seed, accum4, aux4=No
     """One visit of every 4x4 block with per-block priorities (SceneManager.h:193-237), keyed RNG."""
     cam = np.ascontiguousarray(camera)
     x0, y0, w, h = rect
-    st = np.zeros(8, np.uint64)
+    st = np.zeros(10, np.uint64)
     pr = None if block_priority is None else np.ascontiguousarray(block_priority, np.float32)
     self._chk(self.L.sro_render_pass_adaptive(self.h, _p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w), C.c_int32(h),
                                               C.c_uint32(visit_index), C.c_uint64(seed), _p(pr), C.c_int32(threads),

@@ -75,6 +75,7 @@ int sro_scene_package(void* hv, const sro_tri_in* tris, uint32_t n) {
         auto t0 = std::chrono::steady_clock::now();
         package(v, h->scene.geo);
         h->scene.geo.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        h->scene.geo.build_filter_boxes();
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
@@ -87,6 +88,7 @@ int sro_scene_set_packaged(void* hv, const void* nodes, uint32_t n_nodes, const 
     g.avx_bvh.assign((const BVH_AVX*)nodes, (const BVH_AVX*)nodes + n_nodes);
     g.avx_tri_data.assign((const PTri_AVX*)packets, (const PTri_AVX*)packets + n_packets);
     g.tri_data.assign((const PackagedTri*)tris, (const PackagedTri*)tris + n_tris);
+    g.build_filter_boxes();
     return 0;
 }
 
@@ -167,9 +169,9 @@ const float* sro_scene_arccos(void* hv) { return ((Handle*)hv)->scene.tables.arc
 const float* sro_scene_pdf(void* hv) { return ((Handle*)hv)->scene.tables.pdf_lookup.data(); }
 
 // ---- casts ---------------------------------------------------------------
-// counters3 (optional) = {node visits, packet tests, max stack depth}.
+// counters4 (optional) = {node visits, packet tests, max stack depth, packet tests the product's leaf filter saves}.
 int sro_cast_closest(void* hv, const float* org3, const float* dir3, uint32_t n, sro_hit* out, float* advanced_org3,
-                     uint64_t* counters3) {
+                     uint64_t* counters4) {
     Handle* h = (Handle*)hv;
     TraceCounters c;
     try {
@@ -183,7 +185,7 @@ int sro_cast_closest(void* hv, const float* org3, const float* dir3, uint32_t n,
             if (advanced_org3) { advanced_org3[3 * i] = o.X; advanced_org3[3 * i + 1] = o.Y; advanced_org3[3 * i + 2] = o.Z; }
         }
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
-    if (counters3) { counters3[0] = c.nodes; counters3[1] = c.packets; counters3[2] = (uint64_t)c.max_stack; }
+    if (counters4) { counters4[0] = c.nodes; counters4[1] = c.packets; counters4[2] = (uint64_t)c.max_stack; counters4[3] = c.packets_unhittable; }
     return 0;
 }
 
@@ -203,7 +205,8 @@ int sro_cast_shadow(void* hv, const float* org3, const float* dir3, uint32_t n, 
 
 // ---- shading -------------------------------------------------------------
 // process_ray on a batch of rays with per-ray keyed RNG (the wavefront renderer's scheme).
-// stats8 (optional) = {rays_processed, diffuses_cast, shadows_cast, nodes, packets, shadow nodes, shadow packets, hits}
+// stats10 (optional) = {rays_processed, diffuses_cast, shadows_cast, nodes, packets, shadow nodes, shadow packets, hits,
+//                      packets / shadow packets the product's leaf filter saves}
 int sro_process_rays_keyed(void* hv, const float* org3, const float* dir3, const uint64_t* keys, int32_t generation,
                            uint32_t n, float* radiance3, uint64_t* stats8) {
     Handle* h = (Handle*)hv;
@@ -224,6 +227,7 @@ int sro_process_rays_keyed(void* hv, const float* org3, const float* dir3, const
         stats8[0] = st.rays_processed; stats8[1] = st.diffuses_cast; stats8[2] = st.shadows_cast;
         stats8[3] = st.trace.nodes; stats8[4] = st.trace.packets;
         stats8[5] = st.shadow_trace.nodes; stats8[6] = st.shadow_trace.packets; stats8[7] = st.hits;
+        stats8[8] = st.trace.packets_unhittable; stats8[9] = st.shadow_trace.packets_unhittable;
     }
     return 0;
 }
@@ -324,11 +328,12 @@ int sro_render_pass(void* hv, const sro_camera_in* c, int32_t x0, int32_t y0, in
     }
     if (failed) { g_err = "oracle render worker failed"; return 1; }
     if (stats8) {
-        for (int i = 0; i < 8; i++) stats8[i] = 0;
+        for (int i = 0; i < 10; i++) stats8[i] = 0;
         for (auto& s : st) {
             stats8[0] += s.rays_processed; stats8[1] += s.diffuses_cast; stats8[2] += s.shadows_cast;
             stats8[3] += s.trace.nodes; stats8[4] += s.trace.packets;
             stats8[5] += s.shadow_trace.nodes; stats8[6] += s.shadow_trace.packets; stats8[7] += s.hits;
+            stats8[8] += s.trace.packets_unhittable; stats8[9] += s.shadow_trace.packets_unhittable;
         }
     }
     return 0;
@@ -427,11 +432,12 @@ int sro_render_pass_adaptive(void* hv, const sro_camera_in* c, int32_t x0, int32
     }
     if (failed) { g_err = "oracle render worker failed"; return 1; }
     if (stats8) {
-        for (int i = 0; i < 8; i++) stats8[i] = 0;
+        for (int i = 0; i < 10; i++) stats8[i] = 0;
         for (auto& s : st) {
             stats8[0] += s.rays_processed; stats8[1] += s.diffuses_cast; stats8[2] += s.shadows_cast;
             stats8[3] += s.trace.nodes; stats8[4] += s.trace.packets;
             stats8[5] += s.shadow_trace.nodes; stats8[6] += s.shadow_trace.packets; stats8[7] += s.hits;
+            stats8[8] += s.trace.packets_unhittable; stats8[9] += s.shadow_trace.packets_unhittable;
         }
     }
     return 0;

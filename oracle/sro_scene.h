@@ -295,6 +295,44 @@ struct PackagedGeometry {
     std::vector<PTri_AVX> avx_tri_data;
     std::vector<PackagedTri> tri_data;
     double build_seconds = 0;
+    // NOT part of the reference: the product's kernels skip a leaf whose padded tight box the ray misses (the
+    // reference grows leaf boxes from the origin, quirk Q1, so most leaf visits cannot hit anything). The oracle
+    // keeps the reference's traversal and only COUNTS the packet tests such a filter would save, with the same
+    // boxes and the same arithmetic, so the GPU's packet-test counter can be checked exactly.
+    std::vector<float> filter_boxes;        // [node][child][min.xyz, max.xyz], leaf children only (else unused)
+    void build_filter_boxes() {
+        auto bounds = [&](uint32_t first, uint32_t count, float* mn, float* mx) {
+            for (int ax = 0; ax < 3; ax++) { mn[ax] = 3.0e38f; mx[ax] = -3.0e38f; }
+            for (uint32_t p = first; p < first + count; p++) {
+                const PTri_AVX& P = avx_tri_data[p];
+                const float* p1[3] = {P.p1X, P.p1Y, P.p1Z};
+                const float* e1[3] = {P.p1p2X, P.p1p2Y, P.p1p2Z};
+                const float* e2[3] = {P.p1p3X, P.p1p3Y, P.p1p3Z};
+                for (int k = 0; k < 8 && k < (int)P.size; k++)
+                    for (int ax = 0; ax < 3; ax++) {
+                        const float v[3] = {p1[ax][k], p1[ax][k] + e1[ax][k], p1[ax][k] + e2[ax][k]};
+                        for (float c : v) { mn[ax] = std::min(mn[ax], c); mx[ax] = std::max(mx[ax], c); }
+                    }
+            }
+        };
+        float scale = 1e-3f;
+        if (!avx_tri_data.empty()) {
+            float mn[3], mx[3];
+            bounds(0, (uint32_t)avx_tri_data.size(), mn, mx);
+            for (int ax = 0; ax < 3; ax++)
+                if (mx[ax] >= mn[ax]) scale = std::max(scale, std::max(mx[ax] - mn[ax], std::max(std::fabs(mn[ax]), std::fabs(mx[ax]))));
+        }
+        const float pad = 1e-4f * scale;
+        filter_boxes.assign(avx_bvh.size() * 48, 0.0f);
+        for (size_t i = 0; i < avx_bvh.size(); i++)
+            for (int k = 0; k < 8; k++)
+                if (avx_bvh[i].leaf_size[k] > 0) {
+                    float mn[3], mx[3];
+                    bounds(avx_bvh[i].indexes[k], avx_bvh[i].leaf_size[k], mn, mx);
+                    float* f = &filter_boxes[i * 48 + k * 6];
+                    for (int ax = 0; ax < 3; ax++) { f[ax] = mn[ax] - pad; f[3 + ax] = mx[ax] + pad; }
+                }
+    }
 };
 
 // BVH.h:989-1077

@@ -23,7 +23,21 @@ struct TraceCounters {
     uint64_t nodes = 0;      // BVH_AVX::intersection calls (Core.h:70-72)
     uint64_t packets = 0;    // PTri_AVX::intersection_check calls (Core.h:194-229)
     int max_stack = 0;       // deepest stack_index + 1 reached
+    uint64_t packets_unhittable = 0;   // of `packets`: tests in leaves whose padded tight box the ray misses (product's leaf filter)
 };
+
+// the product's leaf filter (raytracing_amd/csrc/srx_trace.hip): conservative slab test against the padded tight box of a
+// leaf; rays with a non-finite 1/d or -o/d component are never filtered
+static inline bool leaf_may_hit(const float* box6, const XYZ& fused, const XYZ& inv) {
+    auto finite = [](float x) { return (bitcast<uint32_t>(x) & 0x7f800000u) != 0x7f800000u; };
+    if (!(finite(fused.X) && finite(fused.Y) && finite(fused.Z) && finite(inv.X) && finite(inv.Y) && finite(inv.Z))) return true;
+    const float x1 = std::fmaf(box6[0], inv.X, fused.X), x2 = std::fmaf(box6[3], inv.X, fused.X);
+    const float y1 = std::fmaf(box6[1], inv.Y, fused.Y), y2 = std::fmaf(box6[4], inv.Y, fused.Y);
+    const float z1 = std::fmaf(box6[2], inv.Z, fused.Z), z2 = std::fmaf(box6[5], inv.Z, fused.Z);
+    const float fmin = std::max(std::min(z1, z2), std::max(std::min(y1, y2), std::min(x1, x2)));
+    const float fmax = std::min(std::max(z1, z2), std::min(std::max(y1, y2), std::max(x1, x2)));
+    return !(fmin > fmax) && !(fmax < 0.0f);
+}
 
 static inline float mm_min(float a, float b) { return a < b ? a : b; }   // vminps: NaN -> b
 static inline float mm_max(float a, float b) { return a > b ? a : b; }   // vmaxps: NaN -> b
@@ -80,15 +94,17 @@ static inline void iterativeBVH_AVX(const PackagedGeometry& data, CastResults& r
     int stack[STACK];
     float distances[STACK];
     int tri_count[STACK];
+    int slot_of[STACK];                           // oracle-side only: node * 8 + child the entry came from
     int stack_index = 0;
-    stack[0] = 0; distances[0] = 0; tri_count[0] = 0;
+    stack[0] = 0; distances[0] = 0; tri_count[0] = 0; slot_of[0] = -1;
     int maxdepth = 1;
     while (stack_index >= 0) {
         const float dist = distances[stack_index];
         const int self_triangles = tri_count[stack_index];
         if (dist >= res.distance) { stack_index--; continue; }
         if (self_triangles == 0) {
-            const BVH_AVX& current = data.avx_bvh[stack[stack_index]];
+            const int current_index = stack[stack_index];
+            const BVH_AVX& current = data.avx_bvh[current_index];
             stack_index--;
             float persist[8];
             node_intersection(current, fused, inv, persist);
@@ -119,10 +135,14 @@ static inline void iterativeBVH_AVX(const PackagedGeometry& data, CastResults& r
                 stack[stack_index] = (int)current.indexes[sel];
                 distances[stack_index] = persist[sel];
                 tri_count[stack_index] = (int)current.leaf_size[sel];
+                slot_of[stack_index] = current_index * 8 + (int)sel;
             }
             if (stack_index + 1 > maxdepth) maxdepth = stack_index + 1;
         } else {
             int start_index = stack[stack_index];
+            if (ctr && !data.filter_boxes.empty() && slot_of[stack_index] >= 0 &&
+                !leaf_may_hit(&data.filter_boxes[(size_t)slot_of[stack_index] * 6], fused, inv))
+                ctr->packets_unhittable += (uint64_t)self_triangles;
             stack_index--;
             for (int i = 0; i < self_triangles; i++) {
                 const PTri_AVX& P = data.avx_tri_data[i + start_index];

@@ -6,7 +6,13 @@
 //           packets of the leaf that follow it. The byte offset of a lane's 16-B slot is
 //           (link << 7) | (lane << 4), one VALU op (the shift drops the flag bits), and the load uses one SGPR
 //           base for both kinds.
-//   GNode   256 B = two 128-B lines. Line A: 8 x {min.x, min.y, min.z, max.x}; line B: 8 x
+//   GNode   512 B = four 128-B lines; the first two hold the reference's child boxes, the last two the FILTER boxes:
+//           8 x {tmin.xyz, tmax.x} / 8 x {tmax.y, tmax.z, 0, 0}. For a leaf child that is the padded tight bound of
+//           the leaf's triangles: the reference grows leaf boxes from the origin (quirk Q1, BVH.h:27-34), so rays
+//           enter most leaves without any chance of a hit (7.4 packet tests per ray on the bench scene, 2.4 with
+//           the filter). A leaf whose filter box is missed is not pushed: it cannot hold a hit, results and visiting
+//           order of everything else are the reference's. For an inner child the filter box is the box itself.
+//           Line A: 8 x {min.x, min.y, min.z, max.x}; line B: 8 x
 //           {max.y, max.z, link, 0}; link == 0 => unused child slot (the root is never a child).
 //           One octet (8 adjacent lanes = the reference's 8 AVX lanes, BVH.h:874-881) reads a node with
 //           two dwordx4 loads per lane, each load covering one contiguous 128-B line per octet.
@@ -29,7 +35,7 @@
 #define SRX_LINK_MORE_SHIFT 25               // bits 25..30: packets of the same leaf after this one
 #define SRX_LINK_MORE_MAX 63u
 
-struct GNode { float4 a[8]; float4 b[8]; };
+struct GNode { float4 a[8]; float4 b[8]; float4 ta[8]; float4 tb[8]; };
 struct GPacket { float4 a[8]; float4 b[8]; float2 c[8]; uint32_t material[8]; uint32_t tri_index[8]; };
 struct GTri {
     float4 r[10];
@@ -39,7 +45,7 @@ struct GTri {
     // r6: t1.z, t2.xyz                 r7: t3.xyz, b1.x
     // r8: b1.yz, b2.xy                 r9: b2.z, b3.xyz
 };
-static_assert(sizeof(GNode) == 256 && sizeof(GPacket) == 384 && sizeof(GTri) == 160, "layout");
+static_assert(sizeof(GNode) == 512 && sizeof(GPacket) == 384 && sizeof(GTri) == 160, "layout");
 
 struct GMaterial {       // srx_material with texture ids resolved to table slots (-1 = constant)
     float color[3];     int color_tex;

@@ -70,7 +70,7 @@ int stack_bound(const uint8_t* nodes, uint32_t n_nodes) {
 extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     if (!desc || !out) SRX_FAIL("srx_scene_create: null argument");
     if (desc->n_nodes == 0 || !desc->nodes) SRX_FAIL("srx_scene_create: scene has no BVH nodes");
-    if (2ull * desc->n_nodes + 3ull * desc->n_packets > (unsigned long long)SRX_LINK_LINE_MASK)
+    if (4ull * desc->n_nodes + 3ull * desc->n_packets > (unsigned long long)SRX_LINK_LINE_MASK)
         SRX_FAIL("srx_scene_create: nodes + packets exceed 4 GB (2^25 lines of 128 B)");
     if (desc->max_generations < 0 || desc->max_generations >= 32) SRX_FAIL("srx_scene_create: max_generations must be in [0, 31]");
     srx_scene* s = new srx_scene();
@@ -81,7 +81,32 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     const uint8_t* rp = (const uint8_t*)desc->packets;
     const uint8_t* rt = (const uint8_t*)desc->tris;
 
-    // ---- nodes: 288-B SoA record (BVH.h:874-881) -> two 128-B child-major lines
+    // ---- filter boxes of the leaves: padded bounds of the triangles of packets [idx, idx + leaf). The pad covers the
+    // rounding of the triangle test against that of the slab test: 1e-4 of the scene's size and coordinate range.
+    auto packet_bounds = [&](uint32_t first, uint32_t count, float* mn, float* mx) {
+        for (int ax = 0; ax < 3; ax++) { mn[ax] = 3.0e38f; mx[ax] = -3.0e38f; }
+        for (uint32_t p = first; p < first + count; p++) {
+            const uint8_t* pk = rp + (size_t)p * SRX_REF_PACKET_BYTES;
+            const int size = (int)(int8_t)pk[420];
+            for (int k = 0; k < 8 && k < size; k++) {
+                for (int ax = 0; ax < 3; ax++) {
+                    const float p1 = rdf(pk, 32 * ax + 4 * k), e1 = rdf(pk, 96 + 32 * ax + 4 * k), e2 = rdf(pk, 192 + 32 * ax + 4 * k);
+                    const float v[3] = {p1, p1 + e1, p1 + e2};
+                    for (float c : v) { mn[ax] = std::min(mn[ax], c); mx[ax] = std::max(mx[ax], c); }
+                }
+            }
+        }
+    };
+    float scene_scale = 1e-3f;
+    if (desc->n_packets) {
+        float mn[3], mx[3];
+        packet_bounds(0, desc->n_packets, mn, mx);
+        for (int ax = 0; ax < 3; ax++)
+            if (mx[ax] >= mn[ax]) scene_scale = std::max(scene_scale, std::max(mx[ax] - mn[ax], std::max(std::fabs(mn[ax]), std::fabs(mx[ax]))));
+    }
+    const float filter_pad = 1e-4f * scene_scale;
+
+    // ---- nodes: 288-B SoA record (BVH.h:874-881) -> two 128-B child-major lines + two lines of filter boxes
     std::vector<GNode> nodes(desc->n_nodes);
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const uint8_t* nd = rn + (size_t)i * SRX_REF_NODE_BYTES;
@@ -91,13 +116,21 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
                 srx_scene_destroy(s); SRX_FAIL("srx_scene_create: node child index out of range");
             }
             uint32_t link = 0;                                        // unused slot (BVH.h:890-895)
-            if (leaf == 0 && idx != 0) link = 2u * idx;
+            if (leaf == 0 && idx != 0) link = 4u * idx;
             if (leaf > 0) {
                 if (leaf - 1u > SRX_LINK_MORE_MAX) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: a leaf with more than 64 packets (512 triangles) is not supported"); }
-                link = SRX_LINK_LEAF | ((leaf - 1u) << SRX_LINK_MORE_SHIFT) | (2u * desc->n_nodes + 3u * idx);
+                link = SRX_LINK_LEAF | ((leaf - 1u) << SRX_LINK_MORE_SHIFT) | (4u * desc->n_nodes + 3u * idx);
             }
             nodes[i].a[k] = make_float4(rdf(nd, 96 + 4 * k), rdf(nd, 128 + 4 * k), rdf(nd, 160 + 4 * k), rdf(nd, 0 + 4 * k));
             nodes[i].b[k] = make_float4(rdf(nd, 32 + 4 * k), rdf(nd, 64 + 4 * k), u2f_host(link), 0.0f);
+            float fmn[3] = {nodes[i].a[k].x, nodes[i].a[k].y, nodes[i].a[k].z};          // inner child: its own box
+            float fmx[3] = {nodes[i].a[k].w, nodes[i].b[k].x, nodes[i].b[k].y};
+            if (leaf > 0) {
+                packet_bounds(idx, leaf, fmn, fmx);
+                for (int ax = 0; ax < 3; ax++) { fmn[ax] -= filter_pad; fmx[ax] += filter_pad; }
+            }
+            nodes[i].ta[k] = make_float4(fmn[0], fmn[1], fmn[2], fmx[0]);
+            nodes[i].tb[k] = make_float4(fmx[1], fmx[2], 0.0f, 0.0f);
         }
     }
     // ---- packets: 448-B record (Primitives.h:127-134) -> three 128-B lanes-major lines

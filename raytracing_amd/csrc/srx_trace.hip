@@ -176,10 +176,13 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     __builtin_amdgcn_wave_barrier();
 
     f3 o, d, inv, fused;
+    bool ray_finite = true;   // the leaf filter applies to rays whose 1/d and -o/d are all finite
     auto load_ray = [&](int j) {
         const float4* src = s_setup + ((size_t)j * SRX_OCTETS_PER_BLOCK + oct) * 3;
         const float4 r0 = src[0], r1 = src[1], r2 = src[2];
         o = f3(r0.x, r0.y, r0.z); d = f3(r0.w, r1.x, r1.y); inv = f3(r1.z, r1.w, r2.x); fused = f3(r2.y, r2.z, r2.w);
+        ray_finite = well_defined(fused.x) && well_defined(fused.y) && well_defined(fused.z) &&
+                     well_defined(inv.x) && well_defined(inv.y) && well_defined(inv.z);
     };
     load_ray(0);
 
@@ -239,12 +242,26 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             const float3 B = *(const float3*)(rec + 128);   // 12 of the slot's 16 bytes: {max.y, max.z, link} / {e1.y, e1.z, e2.x}
             if (!leaf) {
                 n_nodes++;
+                // filter box (srx_device.h): requested with the node's own two lines
+                const float4 TA = *(const float4*)(rec + 256);
+                const float2 TB = *(const float2*)(rec + 384);
                 const uint32_t rb = fast ? node_test<true>(A, B, inv, fused) : node_test<false>(A, B, inv, fused);
                 // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id. result==0 (either sign) is "no hit";
                 // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86): both together are
                 // |result| > (lane == 0 ? 7 : 0)
                 const uint32_t kb = (rb & ~7u) | (uint32_t)sub;
-                const bool valid = (rb & 0x7fffffffu) > zero_key_limit;
+                // a leaf whose padded tight box the ray misses cannot hold a hit and is not pushed (conservative form of the
+                // slab test: equal bounds pass; a ray with a non-finite 1/d or -o/d component is never filtered)
+                bool may_hit;
+                {
+                    const float fx1 = __fmaf_rn(TA.x, inv.x, fused.x), fx2 = __fmaf_rn(TA.w, inv.x, fused.x);
+                    const float fy1 = __fmaf_rn(TA.y, inv.y, fused.y), fy2 = __fmaf_rn(TB.x, inv.y, fused.y);
+                    const float fz1 = __fmaf_rn(TA.z, inv.z, fused.z), fz2 = __fmaf_rn(TB.y, inv.z, fused.z);
+                    const float fmin = hw_max3(hw_min(fz1, fz2), hw_min(fy1, fy2), hw_min(fx1, fx2));
+                    const float fmax = hw_min3(hw_max(fz1, fz2), hw_max(fy1, fy2), hw_max(fx1, fx2));
+                    may_hit = !ray_finite || (!(fmin > fmax) && !(fmax < 0.0f));
+                }
+                const bool valid = (rb & 0x7fffffffu) > zero_key_limit && may_hit;
                 const unsigned long long bal = __ballot(valid);
                 const uint32_t vmask = (uint32_t)(bal >> oct_shift) & 0xFFu;
                 const int nvalid = __popc(vmask);
