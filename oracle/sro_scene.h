@@ -299,7 +299,11 @@ struct PackagedGeometry {
     // reference grows leaf boxes from the origin, quirk Q1, so most leaf visits cannot hit anything). The oracle
     // keeps the reference's traversal and only COUNTS the packet tests such a filter would save, with the same
     // boxes and the same arithmetic, so the GPU's packet-test counter can be checked exactly.
-    std::vector<float> filter_boxes;        // [node][child][min.xyz, max.xyz], leaf children only (else unused)
+    // [node][child][min.xyz, max.xyz] = the planes the product stores per child (srx_scene.hip): the reference's,
+    // except that a leaf box containing the origin on every axis has its planes at 0 replaced by the tight bound of
+    // the leaf's triangles (from the packets, clamped into the reference box)
+    std::vector<float> filter_boxes;
+    float filter_pad = 0.0f;
     void build_filter_boxes() {
         auto bounds = [&](uint32_t first, uint32_t count, float* mn, float* mx) {
             for (int ax = 0; ax < 3; ax++) { mn[ax] = 3.0e38f; mx[ax] = -3.0e38f; }
@@ -322,15 +326,24 @@ struct PackagedGeometry {
             for (int ax = 0; ax < 3; ax++)
                 if (mx[ax] >= mn[ax]) scale = std::max(scale, std::max(mx[ax] - mn[ax], std::max(std::fabs(mn[ax]), std::fabs(mx[ax]))));
         }
-        const float pad = 1e-4f * scale;
+        filter_pad = 1e-4f * scale;
         filter_boxes.assign(avx_bvh.size() * 48, 0.0f);
         for (size_t i = 0; i < avx_bvh.size(); i++)
             for (int k = 0; k < 8; k++)
                 if (avx_bvh[i].leaf_size[k] > 0) {
-                    float mn[3], mx[3];
-                    bounds(avx_bvh[i].indexes[k], avx_bvh[i].leaf_size[k], mn, mx);
+                    const BVH_AVX& n = avx_bvh[i];
+                    const float rmin[3] = {n.minX[k], n.minY[k], n.minZ[k]}, rmax[3] = {n.maxX[k], n.maxY[k], n.maxZ[k]};
                     float* f = &filter_boxes[i * 48 + k * 6];
-                    for (int ax = 0; ax < 3; ax++) { f[ax] = mn[ax] - pad; f[3 + ax] = mx[ax] + pad; }
+                    bool ext = true;
+                    for (int ax = 0; ax < 3; ax++) { f[ax] = rmin[ax]; f[3 + ax] = rmax[ax]; ext = ext && rmin[ax] <= 0.0f && rmax[ax] >= 0.0f; }
+                    if (!ext) continue;
+                    float mn[3], mx[3];
+                    bounds(n.indexes[k], n.leaf_size[k], mn, mx);
+                    for (int ax = 0; ax < 3; ax++) {
+                        if (rmin[ax] == 0.0f && rmax[ax] == 0.0f) { f[ax] = 0.0f; f[3 + ax] = 0.0f; }
+                        else if (rmin[ax] == 0.0f) f[ax] = std::min(std::max(mn[ax], 0.0f), rmax[ax]);
+                        else if (rmax[ax] == 0.0f) f[3 + ax] = std::max(std::min(mx[ax], 0.0f), rmin[ax]);
+                    }
                 }
     }
 };

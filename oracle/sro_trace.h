@@ -26,17 +26,20 @@ struct TraceCounters {
     uint64_t packets_unhittable = 0;   // of `packets`: tests in leaves whose padded tight box the ray misses (product's leaf filter)
 };
 
-// the product's leaf filter (raytracing_amd/csrc/srx_trace.hip): conservative slab test against the padded tight box of a
-// leaf; rays with a non-finite 1/d or -o/d component are never filtered
-static inline bool leaf_may_hit(const float* box6, const XYZ& fused, const XYZ& inv) {
+// the product's leaf filter (node_test in raytracing_amd/csrc/srx_trace.hip): the ray's slab interval against the
+// stored box, widened by pad * max|1/d| at both ends, must be neither empty nor behind the ray; rays with a non-finite
+// 1/d or -o/d component are never filtered
+static inline bool leaf_may_hit(const float* box6, const XYZ& fused, const XYZ& inv, float pad) {
     auto finite = [](float x) { return (bitcast<uint32_t>(x) & 0x7f800000u) != 0x7f800000u; };
     if (!(finite(fused.X) && finite(fused.Y) && finite(fused.Z) && finite(inv.X) && finite(inv.Y) && finite(inv.Z))) return true;
+    const float pt = pad * std::max(std::max(std::fabs(inv.X), std::fabs(inv.Y)), std::fabs(inv.Z));
+    const float pt2 = pt + pt, npt = -pt;
     const float x1 = std::fmaf(box6[0], inv.X, fused.X), x2 = std::fmaf(box6[3], inv.X, fused.X);
     const float y1 = std::fmaf(box6[1], inv.Y, fused.Y), y2 = std::fmaf(box6[4], inv.Y, fused.Y);
     const float z1 = std::fmaf(box6[2], inv.Z, fused.Z), z2 = std::fmaf(box6[5], inv.Z, fused.Z);
-    const float fmin = std::max(std::min(z1, z2), std::max(std::min(y1, y2), std::min(x1, x2)));
-    const float fmax = std::min(std::max(z1, z2), std::min(std::max(y1, y2), std::max(x1, x2)));
-    return !(fmin > fmax) && !(fmax < 0.0f);
+    const float smin = std::max(std::min(z1, z2), std::max(std::min(y1, y2), std::min(x1, x2)));
+    const float smax = std::min(std::max(z1, z2), std::min(std::max(y1, y2), std::max(x1, x2)));
+    return !(smin - smax > pt2) && !(smax < npt);
 }
 
 static inline float mm_min(float a, float b) { return a < b ? a : b; }   // vminps: NaN -> b
@@ -141,7 +144,7 @@ static inline void iterativeBVH_AVX(const PackagedGeometry& data, CastResults& r
         } else {
             int start_index = stack[stack_index];
             if (ctr && !data.filter_boxes.empty() && slot_of[stack_index] >= 0 &&
-                !leaf_may_hit(&data.filter_boxes[(size_t)slot_of[stack_index] * 6], fused, inv))
+                !leaf_may_hit(&data.filter_boxes[(size_t)slot_of[stack_index] * 6], fused, inv, data.filter_pad))
                 ctr->packets_unhittable += (uint64_t)self_triangles;
             stack_index--;
             for (int i = 0; i < self_triangles; i++) {

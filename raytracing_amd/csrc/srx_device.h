@@ -2,16 +2,17 @@
 //
 // HBM layouts (all immutable after srx_scene_create):
 //   geom    ONE allocation of 128-B lines: all nodes (2 lines each), then all packets (3 lines each). A link
-//           is a line index into it (bits 0..24); bit 31 marks a leaf's packet and bits 25..30 count the
+//           is a line index into it (bits 0..24); bit 31 marks a leaf's packet, bit 30 an origin-extended leaf box and bits 25..29 count the
 //           packets of the leaf that follow it. The byte offset of a lane's 16-B slot is
 //           (link << 7) | (lane << 4), one VALU op (the shift drops the flag bits), and the load uses one SGPR
 //           base for both kinds.
-//   GNode   512 B = four 128-B lines; the first two hold the reference's child boxes, the last two the FILTER boxes:
-//           8 x {tmin.xyz, tmax.x} / 8 x {tmax.y, tmax.z, 0, 0}. For a leaf child that is the padded tight bound of
-//           the leaf's triangles: the reference grows leaf boxes from the origin (quirk Q1, BVH.h:27-34), so rays
-//           enter most leaves without any chance of a hit (7.4 packet tests per ray on the bench scene, 2.4 with
-//           the filter). A leaf whose filter box is missed is not pushed: it cannot hold a hit, results and visiting
-//           order of everything else are the reference's. For an inner child the filter box is the box itself.
+//   GNode   256 B = two 128-B lines of child boxes. For a leaf child the reference's box is the bound of the
+//           leaf's triangles grown to contain the ORIGIN (quirk Q1, BVH.h:27-34), so rays enter most leaves without
+//           any chance of a hit (7.4 packet tests per ray on the bench scene). Such a child stores its TIGHT planes
+//           and sets SRX_LINK_EXT in its link: the reference's slab interval per axis is then
+//           [min(near, z), max(far, z)] with z = fma(0, 1/d, -o/d) (exact, see k_trace), and the same six plane
+//           times, padded, tell whether the ray can hit the leaf at all: if not, the leaf is not pushed (2.4 packet
+//           tests per ray). Results, visiting order and node tests are the reference's.
 //           Line A: 8 x {min.x, min.y, min.z, max.x}; line B: 8 x
 //           {max.y, max.z, link, 0}; link == 0 => unused child slot (the root is never a child).
 //           One octet (8 adjacent lanes = the reference's 8 AVX lanes, BVH.h:874-881) reads a node with
@@ -32,10 +33,11 @@
 #define SRX_MISS_DISTANCE 99999999999999999.f   // Coredefs.cpp:9
 #define SRX_LINK_LEAF 0x80000000u
 #define SRX_LINK_LINE_MASK 0x01FFFFFFu       // 2^25 lines of 128 B = 4 GB of nodes + packets
-#define SRX_LINK_MORE_SHIFT 25               // bits 25..30: packets of the same leaf after this one
-#define SRX_LINK_MORE_MAX 63u
+#define SRX_LINK_MORE_SHIFT 25               // bits 25..29: packets of the same leaf after this one
+#define SRX_LINK_MORE_MAX 31u
+#define SRX_LINK_EXT 0x40000000u             // leaf child whose reference box = tight planes stored here, grown to the origin
 
-struct GNode { float4 a[8]; float4 b[8]; float4 ta[8]; float4 tb[8]; };
+struct GNode { float4 a[8]; float4 b[8]; };
 struct GPacket { float4 a[8]; float4 b[8]; float2 c[8]; uint32_t material[8]; uint32_t tri_index[8]; };
 struct GTri {
     float4 r[10];
@@ -45,7 +47,7 @@ struct GTri {
     // r6: t1.z, t2.xyz                 r7: t3.xyz, b1.x
     // r8: b1.yz, b2.xy                 r9: b2.z, b3.xyz
 };
-static_assert(sizeof(GNode) == 512 && sizeof(GPacket) == 384 && sizeof(GTri) == 160, "layout");
+static_assert(sizeof(GNode) == 256 && sizeof(GPacket) == 384 && sizeof(GTri) == 160, "layout");
 
 struct GMaterial {       // srx_material with texture ids resolved to table slots (-1 = constant)
     float color[3];     int color_tex;
@@ -79,6 +81,7 @@ struct GScene {
     int max_generations;
     int bounce_count[32];         // int(monte_carlo_max * pow(modifier, g)), host-computed (Core.h:428)
     int stack_depth;              // LDS entries per octet (worst-case bound of this tree)
+    float filter_pad;             // leaf filter: planes are pushed out by this distance (1e-4 of the scene's size)
 };
 
 // ---- ray / hit / shadow records of the wavefront queues --------------------

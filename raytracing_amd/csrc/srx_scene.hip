@@ -70,7 +70,7 @@ int stack_bound(const uint8_t* nodes, uint32_t n_nodes) {
 extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     if (!desc || !out) SRX_FAIL("srx_scene_create: null argument");
     if (desc->n_nodes == 0 || !desc->nodes) SRX_FAIL("srx_scene_create: scene has no BVH nodes");
-    if (4ull * desc->n_nodes + 3ull * desc->n_packets > (unsigned long long)SRX_LINK_LINE_MASK)
+    if (2ull * desc->n_nodes + 3ull * desc->n_packets > (unsigned long long)SRX_LINK_LINE_MASK)
         SRX_FAIL("srx_scene_create: nodes + packets exceed 4 GB (2^25 lines of 128 B)");
     if (desc->max_generations < 0 || desc->max_generations >= 32) SRX_FAIL("srx_scene_create: max_generations must be in [0, 31]");
     srx_scene* s = new srx_scene();
@@ -81,7 +81,7 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     const uint8_t* rp = (const uint8_t*)desc->packets;
     const uint8_t* rt = (const uint8_t*)desc->tris;
 
-    // ---- filter boxes of the leaves: padded bounds of the triangles of packets [idx, idx + leaf). The pad covers the
+    // ---- leaf filter: bounds of the triangles of packets [idx, idx + leaf), and the pad that covers the
     // rounding of the triangle test against that of the slab test: 1e-4 of the scene's size and coordinate range.
     auto packet_bounds = [&](uint32_t first, uint32_t count, float* mn, float* mx) {
         for (int ax = 0; ax < 3; ax++) { mn[ax] = 3.0e38f; mx[ax] = -3.0e38f; }
@@ -104,9 +104,9 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
         for (int ax = 0; ax < 3; ax++)
             if (mx[ax] >= mn[ax]) scene_scale = std::max(scene_scale, std::max(mx[ax] - mn[ax], std::max(std::fabs(mn[ax]), std::fabs(mx[ax]))));
     }
-    const float filter_pad = 1e-4f * scene_scale;
+    s->g.filter_pad = 1e-4f * scene_scale;
 
-    // ---- nodes: 288-B SoA record (BVH.h:874-881) -> two 128-B child-major lines + two lines of filter boxes
+    // ---- nodes: 288-B SoA record (BVH.h:874-881) -> two 128-B child-major lines
     std::vector<GNode> nodes(desc->n_nodes);
     for (uint32_t i = 0; i < desc->n_nodes; i++) {
         const uint8_t* nd = rn + (size_t)i * SRX_REF_NODE_BYTES;
@@ -116,21 +116,31 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
                 srx_scene_destroy(s); SRX_FAIL("srx_scene_create: node child index out of range");
             }
             uint32_t link = 0;                                        // unused slot (BVH.h:890-895)
-            if (leaf == 0 && idx != 0) link = 4u * idx;
+            if (leaf == 0 && idx != 0) link = 2u * idx;
             if (leaf > 0) {
-                if (leaf - 1u > SRX_LINK_MORE_MAX) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: a leaf with more than 64 packets (512 triangles) is not supported"); }
-                link = SRX_LINK_LEAF | ((leaf - 1u) << SRX_LINK_MORE_SHIFT) | (4u * desc->n_nodes + 3u * idx);
+                if (leaf - 1u > SRX_LINK_MORE_MAX) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: a leaf with more than 32 packets (256 triangles) is not supported"); }
+                link = SRX_LINK_LEAF | ((leaf - 1u) << SRX_LINK_MORE_SHIFT) | (2u * desc->n_nodes + 3u * idx);
             }
-            nodes[i].a[k] = make_float4(rdf(nd, 96 + 4 * k), rdf(nd, 128 + 4 * k), rdf(nd, 160 + 4 * k), rdf(nd, 0 + 4 * k));
-            nodes[i].b[k] = make_float4(rdf(nd, 32 + 4 * k), rdf(nd, 64 + 4 * k), u2f_host(link), 0.0f);
-            float fmn[3] = {nodes[i].a[k].x, nodes[i].a[k].y, nodes[i].a[k].z};          // inner child: its own box
-            float fmx[3] = {nodes[i].a[k].w, nodes[i].b[k].x, nodes[i].b[k].y};
-            if (leaf > 0) {
-                packet_bounds(idx, leaf, fmn, fmx);
-                for (int ax = 0; ax < 3; ax++) { fmn[ax] -= filter_pad; fmx[ax] += filter_pad; }
+            float rmin[3] = {rdf(nd, 96 + 4 * k), rdf(nd, 128 + 4 * k), rdf(nd, 160 + 4 * k)};
+            float rmax[3] = {rdf(nd, 0 + 4 * k), rdf(nd, 32 + 4 * k), rdf(nd, 64 + 4 * k)};
+            float smin[3] = {rmin[0], rmin[1], rmin[2]}, smax[3] = {rmax[0], rmax[1], rmax[2]};
+            // A leaf box that contains the origin on every axis (all ordinary leaves, quirk Q1): a reference plane at
+            // 0 hides the tight plane, which is taken from the packets (to an ulp: it only feeds the padded filter and
+            // an ordering the clamp keeps); a non-zero reference plane IS the tight plane.
+            bool ext = leaf > 0;
+            for (int ax = 0; ax < 3 && ext; ax++) ext = (rmin[ax] <= 0.0f) && (rmax[ax] >= 0.0f);
+            if (ext) {
+                float pmn[3], pmx[3];
+                packet_bounds(idx, leaf, pmn, pmx);
+                for (int ax = 0; ax < 3; ax++) {
+                    if (rmin[ax] == 0.0f && rmax[ax] == 0.0f) { smin[ax] = 0.0f; smax[ax] = 0.0f; }
+                    else if (rmin[ax] == 0.0f) smin[ax] = std::min(std::max(pmn[ax], 0.0f), rmax[ax]);
+                    else if (rmax[ax] == 0.0f) smax[ax] = std::max(std::min(pmx[ax], 0.0f), rmin[ax]);
+                }
+                link |= SRX_LINK_EXT;
             }
-            nodes[i].ta[k] = make_float4(fmn[0], fmn[1], fmn[2], fmx[0]);
-            nodes[i].tb[k] = make_float4(fmx[1], fmx[2], 0.0f, 0.0f);
+            nodes[i].a[k] = make_float4(smin[0], smin[1], smin[2], smax[0]);
+            nodes[i].b[k] = make_float4(smax[1], smax[2], u2f_host(link), 0.0f);
         }
     }
     // ---- packets: 448-B record (Primitives.h:127-134) -> three 128-B lanes-major lines

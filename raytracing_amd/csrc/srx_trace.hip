@@ -93,19 +93,44 @@ __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; a
 __device__ __forceinline__ float x86_min(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float x86_max(float a, float b) { return a > b ? a : b; }
 
-// One child box per lane (BVH.h:940-988). Returns the raw result bits (tmin or 0).
+// One child box per lane (BVH.h:940-988). Returns the raw result bits (tmin or 0) of the REFERENCE's box and, in
+// may_hit, whether the ray can hit anything inside the stored (tight) box at all.
+//   Stored planes (srx_device.h): the reference's, except for a leaf child with SRX_LINK_EXT, whose reference box is
+// the stored box grown to the origin. For such a child the reference's plane on each side of an axis is either the
+// stored one or 0, and 0 lies between the stored planes or beyond them on the side the stored plane was clamped from;
+// fma(x, 1/d, -o/d) is monotone in x, so the reference's slab interval is [min(near, z), max(far, z)] with
+// z = fma(0, 1/d, -o/d), which is -o/d itself up to the sign of a zero (a zero result is "no hit" either way).
+//   Filter: the stored box's interval, widened by pt = pad * max|1/d| on both ends (pt2 = 2 pt, npt = -pt), must not
+// be empty or behind the ray. An inner child that the reference test accepts always passes it.
 template <bool FAST>
-__device__ __forceinline__ uint32_t node_test(const float4 A, const float3 B, const f3 inv, const f3 fused) {
+__device__ __forceinline__ uint32_t node_test(const float4 A, const float3 B, const f3 inv, const f3 fused,
+                                              const float pt2, const float npt, bool& may_hit) {
     const float tx1 = __fmaf_rn(A.x, inv.x, fused.x), tx2 = __fmaf_rn(A.w, inv.x, fused.x);
     const float ty1 = __fmaf_rn(A.y, inv.y, fused.y), ty2 = __fmaf_rn(B.x, inv.y, fused.y);
     const float tz1 = __fmaf_rn(A.z, inv.z, fused.z), tz2 = __fmaf_rn(B.y, inv.z, fused.z);
+    const bool ext = (f2u(B.z) & SRX_LINK_EXT) != 0u;
+    const float nx = hw_min(tx1, tx2), ny = hw_min(ty1, ty2), nz = hw_min(tz1, tz2);
+    const float fx = hw_max(tx1, tx2), fy = hw_max(ty1, ty2), fz = hw_max(tz1, tz2);
+    const float smin = hw_max3(nz, ny, nx), smax = hw_min3(fz, fy, fx);
+    may_hit = !(smin - smax > pt2) && !(smax < npt);
     float tmin, tmax;
     if (FAST) {
-        tmin = hw_max3(hw_min(tz1, tz2), hw_min(ty1, ty2), hw_min(tx1, tx2));
-        tmax = hw_min3(hw_max(tz1, tz2), hw_max(ty1, ty2), hw_max(tx1, tx2));
+        const float emin = hw_max3(hw_min(nz, fused.z), hw_min(ny, fused.y), hw_min(nx, fused.x));
+        const float emax = hw_min3(hw_max(fz, fused.z), hw_max(fy, fused.y), hw_max(fx, fused.x));
+        tmin = ext ? emin : smin;
+        tmax = ext ? emax : smax;
     } else {
-        const float tminx = x86_min(tx1, tx2), tminy = x86_min(ty1, ty2), tminz = x86_min(tz1, tz2);
-        const float tmaxx = x86_max(tx1, tx2), tmaxy = x86_max(ty1, ty2), tmaxz = x86_max(tz1, tz2);
+        // a ray of the wave has a non-finite 1/d or -o/d: the reference's planes and x86 min/max, literally
+        float rx1 = A.x, ry1 = A.y, rz1 = A.z, rx2 = A.w, ry2 = B.x, rz2 = B.y;
+        if (ext) {
+            rx1 = rx1 < 0.0f ? rx1 : 0.0f; ry1 = ry1 < 0.0f ? ry1 : 0.0f; rz1 = rz1 < 0.0f ? rz1 : 0.0f;
+            rx2 = rx2 > 0.0f ? rx2 : 0.0f; ry2 = ry2 > 0.0f ? ry2 : 0.0f; rz2 = rz2 > 0.0f ? rz2 : 0.0f;
+        }
+        const float ux1 = __fmaf_rn(rx1, inv.x, fused.x), ux2 = __fmaf_rn(rx2, inv.x, fused.x);
+        const float uy1 = __fmaf_rn(ry1, inv.y, fused.y), uy2 = __fmaf_rn(ry2, inv.y, fused.y);
+        const float uz1 = __fmaf_rn(rz1, inv.z, fused.z), uz2 = __fmaf_rn(rz2, inv.z, fused.z);
+        const float tminx = x86_min(ux1, ux2), tminy = x86_min(uy1, uy2), tminz = x86_min(uz1, uz2);
+        const float tmaxx = x86_max(ux1, ux2), tmaxy = x86_max(uy1, uy2), tmaxz = x86_max(uz1, uz2);
         tmin = x86_max(tminz, x86_max(tminy, tminx));
         tmax = x86_min(tmaxz, x86_min(tmaxy, tmaxx));
     }
@@ -177,12 +202,15 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
 
     f3 o, d, inv, fused;
     bool ray_finite = true;   // the leaf filter applies to rays whose 1/d and -o/d are all finite
+    float pt2 = 0.0f, npt = 0.0f;   // the filter's widening of this ray's slab interval (node_test)
     auto load_ray = [&](int j) {
         const float4* src = s_setup + ((size_t)j * SRX_OCTETS_PER_BLOCK + oct) * 3;
         const float4 r0 = src[0], r1 = src[1], r2 = src[2];
         o = f3(r0.x, r0.y, r0.z); d = f3(r0.w, r1.x, r1.y); inv = f3(r1.z, r1.w, r2.x); fused = f3(r2.y, r2.z, r2.w);
         ray_finite = well_defined(fused.x) && well_defined(fused.y) && well_defined(fused.z) &&
                      well_defined(inv.x) && well_defined(inv.y) && well_defined(inv.z);
+        const float pt = sc.filter_pad * fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
+        pt2 = pt + pt; npt = -pt;
     };
     load_ray(0);
 
@@ -242,26 +270,15 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             const float3 B = *(const float3*)(rec + 128);   // 12 of the slot's 16 bytes: {max.y, max.z, link} / {e1.y, e1.z, e2.x}
             if (!leaf) {
                 n_nodes++;
-                // filter box (srx_device.h): requested with the node's own two lines
-                const float4 TA = *(const float4*)(rec + 256);
-                const float2 TB = *(const float2*)(rec + 384);
-                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused) : node_test<false>(A, B, inv, fused);
+                bool may_hit;
+                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused, pt2, npt, may_hit)
+                                         : node_test<false>(A, B, inv, fused, pt2, npt, may_hit);
                 // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id. result==0 (either sign) is "no hit";
                 // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86): both together are
                 // |result| > (lane == 0 ? 7 : 0)
                 const uint32_t kb = (rb & ~7u) | (uint32_t)sub;
-                // a leaf whose padded tight box the ray misses cannot hold a hit and is not pushed (conservative form of the
-                // slab test: equal bounds pass; a ray with a non-finite 1/d or -o/d component is never filtered)
-                bool may_hit;
-                {
-                    const float fx1 = __fmaf_rn(TA.x, inv.x, fused.x), fx2 = __fmaf_rn(TA.w, inv.x, fused.x);
-                    const float fy1 = __fmaf_rn(TA.y, inv.y, fused.y), fy2 = __fmaf_rn(TB.x, inv.y, fused.y);
-                    const float fz1 = __fmaf_rn(TA.z, inv.z, fused.z), fz2 = __fmaf_rn(TB.y, inv.z, fused.z);
-                    const float fmin = hw_max3(hw_min(fz1, fz2), hw_min(fy1, fy2), hw_min(fx1, fx2));
-                    const float fmax = hw_min3(hw_max(fz1, fz2), hw_max(fy1, fy2), hw_max(fx1, fx2));
-                    may_hit = !ray_finite || (!(fmin > fmax) && !(fmax < 0.0f));
-                }
-                const bool valid = (rb & 0x7fffffffu) > zero_key_limit && may_hit;
+                // a leaf the ray cannot hit is not pushed (a ray with a non-finite 1/d or -o/d component is never filtered)
+                const bool valid = (rb & 0x7fffffffu) > zero_key_limit && (may_hit || !ray_finite);
                 const unsigned long long bal = __ballot(valid);
                 const uint32_t vmask = (uint32_t)(bal >> oct_shift) & 0xFFu;
                 const int nvalid = __popc(vmask);
