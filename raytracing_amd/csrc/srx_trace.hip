@@ -161,6 +161,8 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const uint32_t ray0 = lblock * SRX_RAYS_PER_BLOCK + oct;
     constexpr int K = SRX_RAYS_PER_OCTET;
     float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {o, d.x}, {d.yz, inv.xy}, {inv.z, fused}
+    float* const s_pt = (float*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening
+    // (LDS per wave = 64 B x stack depth + 1 792 B; 5 120 B is what 32 waves per CU can have)
 
     // ---- set-up of all K rays of the octet at once: lane `sub` prepares ray `sub`
     bool fast;
@@ -185,11 +187,15 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         const bool finite6 = well_defined(sfused.x) && well_defined(sfused.y) && well_defined(sfused.z) &&
                              well_defined(sinv.x) && well_defined(sinv.y) && well_defined(sinv.z);
         fast = !__any(mine && !finite6);   // wave-uniform
+        // the leaf filter's widening of this ray's slab interval (node_test); infinite = never filtered, for a ray
+        // with a non-finite 1/d or -o/d component
+        const float spt = finite6 ? sc.filter_pad * fmaxf(fmaxf(fabsf(sinv.x), fabsf(sinv.y)), fabsf(sinv.z)) : __builtin_inff();
         if (sub < K) {
             float4* dst = s_setup + ((size_t)sub * SRX_OCTETS_PER_BLOCK + oct) * 3;
             dst[0] = make_float4(so.x, so.y, so.z, sd.x);
             dst[1] = make_float4(sd.y, sd.z, sinv.x, sinv.y);
             dst[2] = make_float4(sinv.z, sfused.x, sfused.y, sfused.z);
+            s_pt[sub * SRX_OCTETS_PER_BLOCK + oct] = spt;
         }
     }
     // rays of this octet that exist: indices grow with j, so they are j = 0 .. cnt-1
@@ -200,17 +206,17 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const bool live = cnt > 0;
     __builtin_amdgcn_wave_barrier();
 
-    f3 o, d, inv, fused;
-    bool ray_finite = true;   // the leaf filter applies to rays whose 1/d and -o/d are all finite
-    float pt2 = 0.0f, npt = 0.0f;   // the filter's widening of this ray's slab interval (node_test)
+    // per ray in registers: what the node test needs (1/d, -o/d); origin and direction stay in LDS and are read by the
+    // few trips that need them (packet tests, results): fewer loop-carried registers
+    f3 inv, fused;
+    const float4* ray_setup = s_setup;
+    float pt2 = 0.0f, npt = 0.0f;
     auto load_ray = [&](int j) {
-        const float4* src = s_setup + ((size_t)j * SRX_OCTETS_PER_BLOCK + oct) * 3;
-        const float4 r0 = src[0], r1 = src[1], r2 = src[2];
-        o = f3(r0.x, r0.y, r0.z); d = f3(r0.w, r1.x, r1.y); inv = f3(r1.z, r1.w, r2.x); fused = f3(r2.y, r2.z, r2.w);
-        ray_finite = well_defined(fused.x) && well_defined(fused.y) && well_defined(fused.z) &&
-                     well_defined(inv.x) && well_defined(inv.y) && well_defined(inv.z);
-        const float pt = sc.filter_pad * fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
-        pt2 = pt + pt; npt = -pt;
+        ray_setup = s_setup + ((size_t)j * SRX_OCTETS_PER_BLOCK + oct) * 3;
+        const float2 r1 = *(const float2*)((const char*)ray_setup + 24);
+        const float4 r2 = ray_setup[2];
+        const float pt = s_pt[j * SRX_OCTETS_PER_BLOCK + oct];
+        pt2 = pt + pt; npt = -pt; inv = f3(r1.x, r1.y, r2.x); fused = f3(r2.y, r2.z, r2.w);
     };
     load_ray(0);
 
@@ -233,6 +239,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 h.u = hit ? u2f(b.x) : -1.0f; h.v = hit ? u2f(b.y) : -1.0f;
                 a.hits[r] = h;
                 if (a.advanced_org3) {
+                    const float4 r0 = ray_setup[0];
+                    const float2 r1 = *(const float2*)(ray_setup + 1);
+                    const f3 o(r0.x, r0.y, r0.z), d(r0.w, r1.x, r1.y);
                     const f3 p = o + (best_t * d) * 0.999f;
                     a.advanced_org3[3 * (size_t)r] = p.x; a.advanced_org3[3 * (size_t)r + 1] = p.y; a.advanced_org3[3 * (size_t)r + 2] = p.z;
                 }
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     if (sub == 0) s_stack[oct] = 0ull;   // root: node 0, distance 0, no packets (Core.h:59-61)
     __builtin_amdgcn_wave_barrier();
 
-    while (__any(sp >= 0)) {
+    while (__builtin_amdgcn_ballot_w64(sp >= 0) != 0ull) {
         // pop until an entry survives the distance cull (Core.h:63-68)
         uint32_t link = 0;
         bool go = false;
@@ -277,9 +286,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86): both together are
                 // |result| > (lane == 0 ? 7 : 0)
                 const uint32_t kb = (rb & ~7u) | (uint32_t)sub;
-                // a leaf the ray cannot hit is not pushed (a ray with a non-finite 1/d or -o/d component is never filtered)
-                const bool valid = (rb & 0x7fffffffu) > zero_key_limit && (may_hit || !ray_finite);
-                const unsigned long long bal = __ballot(valid);
+                // a leaf the ray cannot hit is not pushed
+                const bool valid = (rb & 0x7fffffffu) > zero_key_limit && may_hit;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid);
                 const uint32_t vmask = (uint32_t)(bal >> oct_shift) & 0xFFu;
                 const int nvalid = __popc(vmask);
                 int rank;
@@ -301,6 +310,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 // The rest of a multi-packet leaf goes back on top with distance -inf: it is never culled, exactly
                 // like the reference's inner `for` over the leaf's packets (Core.h:179).
                 const float2 C = *(const float2*)(rec + 256 - 8 * sub);   // third line: 8 x {e2.y, e2.z}, 8-B slots
+                const float4 r0 = ray_setup[0];
+                const float2 r1 = *(const float2*)(ray_setup + 1);
+                const f3 o(r0.x, r0.y, r0.z), d(r0.w, r1.x, r1.y);
                 if ((link & (SRX_LINK_MORE_MAX << SRX_LINK_MORE_SHIFT)) != 0u) {
                     sp++;   // next packet of the leaf: line + 3, one packet fewer to follow
                     if (sub == 0) s_stack[sp * SRX_OCTETS_PER_BLOCK + oct] = (0xFF800000ull << 32) | (link + 3u - (1u << SRX_LINK_MORE_SHIFT));
@@ -322,13 +334,13 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 const bool pass = (uu >= 0.0f) && (vv >= 0.0f) && ((uu + vv) <= 1.0f);
                 // closest-hit select (Core.h:231-239): lanes in order, strict '<' => lowest lane wins ties
                 const bool cand = pass && (tt > 0.0f) && (tt < best_t);
-                if (__ballot(cand) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
                     const uint32_t tb = cand ? f2u(tt) : 0xFFFFFFFFu;
                     const uint32_t m = octet_min_u32(tb);
                     if (m != 0xFFFFFFFFu) {
                         best_t = u2f(m);
                         if (MODE == 0) {
-                            const unsigned long long wb = __ballot(tb == m);
+                            const unsigned long long wb = __builtin_amdgcn_ballot_w64(tb == m);
                             const int w = __ffs((int)((uint32_t)(wb >> oct_shift) & 0xFFu)) - 1;
                             // the winning lane records (u, v, where its material and tri_index are) for its octet
                             if (sub == w) s_best[oct] = make_uint4(f2u(uu), f2u(vv), off + 256u + 64u - 12u * (uint32_t)sub, 0u);
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         if (K > 1) {
             // an octet whose ray has ended takes its next one: result out, set-up in from LDS, stack = {root}
             const bool next_ray = sp < 0 && cur + 1 < cnt;
-            if (__any(next_ray)) {
+            if (__builtin_amdgcn_ballot_w64(next_ray) != 0ull) {
                 if (next_ray) {
                     finish(ray);
                     cur++;
@@ -379,7 +391,7 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
     uint32_t blocks = (a.n + SRX_RAYS_PER_BLOCK - 1) / SRX_RAYS_PER_BLOCK;
     blocks = (blocks + 7u) & ~7u;   // multiple of 8 so the XCD map covers every logical block exactly once
     const size_t lds = (size_t)sc.stack_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
-                       (size_t)SRX_RAYS_PER_BLOCK * 3 * sizeof(float4);
+                       (size_t)SRX_RAYS_PER_BLOCK * (3 * sizeof(float4) + sizeof(float));
     if (mode == 0) hipLaunchKernelGGL(k_trace<0>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
     else if (mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
     else hipLaunchKernelGGL(k_trace<2>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
