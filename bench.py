@@ -244,6 +244,7 @@ def main():
                 "shadow_rays_per_step": agg["shadows_cast"] / args.steps,
                 "ray_capacity": args.ray_capacity,
                 "scene_package_s": t_pack,
+                "stack_depth": RE.stack_bound(),
             },
             "roofline": {
                 "kernel": "k_trace<0> (closest-hit traversal)",

@@ -13,6 +13,7 @@
 // scene's tree, computed on the host (the reference reserves 256 entries, Scene.h:181).
 // Bound: HBM/L2 gather bandwidth + latency (no MFMA work here); see DESIGN.md.
 #include "srx_kernels.h"
+#include <cstdlib>
 
 // One wave per block: a finished wave frees its slot at once instead of waiting for three block mates whose rays
 // run longer (measured: 256 -> 64 threads per block = -5 % kernel time on incoherent rays).
@@ -23,12 +24,13 @@
 // Rays per octet: an octet works through K rays one after the other, so a wave carries 8 K rays and ends when its
 // slowest OCTET ends: the sum of K ray lengths varies less than one length (K = 4 saves 7 % of the wave-trips). All K set-ups (the IEEE divides of Core.h:53-54) are computed up
 // front, one ray per lane, and parked in LDS; switching rays costs three LDS reads.
-// Measured (bench workload): K = 1 / 2 / 3 / 4 / 5 / 6 / 8 -> 1002 / 1007 / 1031 / 1041 / 1044 / 944 / 950 Mrays/s (the
+// Measured (bench workload, before K became a template parameter): K = 1 / 2 / 3 / 4 / 5 / 6 / 8 -> 1002 / 1007 / 1031 / 1041 / 1044 / 944 / 950 Mrays/s (the
 // shadow kernel gains 12 %, the closest-hit kernel nothing; from K = 6 the LDS footprint costs a wave per SIMD).
-#ifndef SRX_RAYS_PER_OCTET
-#define SRX_RAYS_PER_OCTET 4
-#endif
-#define SRX_RAYS_PER_BLOCK (SRX_OCTETS_PER_BLOCK * SRX_RAYS_PER_OCTET)
+// K is a template parameter: the launcher takes the largest of 4 / 2 / 1 whose LDS footprint (64 B x stack depth +
+// 128 + 416 K bytes per wave) still lets 32 waves share a CU's 160 KB, because near 8 waves per SIMD the kernel's time
+// goes 1:1 with the waves in flight. Results do not depend on K.
+#define SRX_RAYS_PER_OCTET_MAX 4
+#define SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY 5120u
 
 
 // ---- cross-lane helpers inside an octet, all DPP (no LDS crossbar): quad_perm for lane^1, ^2, ^3 and
@@ -139,8 +141,9 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float3 B, co
 }
 
 // MODE 0: closest hit.  MODE 1: shadow, API form (writes lit[]).  MODE 2: shadow, renderer queue form.
-template <int MODE>
+template <int MODE, int K>
 __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArgs a) {
+    constexpr uint32_t SRX_RAYS_PER_BLOCK = SRX_OCTETS_PER_BLOCK * K;
     // LDS: traversal stack [depth][octets of the block] of (tmin bits << 32 | link), then one 16-B best-hit record per octet
     extern __shared__ unsigned long long s_mem[];
     unsigned long long* const s_stack = s_mem;
@@ -159,7 +162,6 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     // ray j of this octet; the block's rays are contiguous in the queue
     const uint32_t ray0 = lblock * SRX_RAYS_PER_BLOCK + oct;
-    constexpr int K = SRX_RAYS_PER_OCTET;
     float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {o, d.x}, {d.yz, inv.xy}, {inv.z, fused}
     float* const s_pt = (float*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening
     // (LDS per wave = 64 B x stack depth + 1 792 B; 5 120 B is what 32 waves per CU can have)
@@ -386,14 +388,29 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     }
 }
 
+static size_t trace_lds_bytes(int stack_depth, int k) {
+    return (size_t)stack_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
+           (size_t)SRX_OCTETS_PER_BLOCK * k * (3 * sizeof(float4) + sizeof(float));
+}
+
+template <int K>
+static void launch_k(int mode, uint32_t blocks, size_t lds, const GScene& sc, const TraceArgs& a, hipStream_t stream) {
+    if (mode == 0) hipLaunchKernelGGL((k_trace<0, K>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_trace<1, K>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+    else hipLaunchKernelGGL((k_trace<2, K>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+}
+
 extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& a, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;
-    uint32_t blocks = (a.n + SRX_RAYS_PER_BLOCK - 1) / SRX_RAYS_PER_BLOCK;
+    int k = SRX_RAYS_PER_OCTET_MAX;
+    while (k > 1 && trace_lds_bytes(sc.stack_depth, k) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) k >>= 1;
+    if (const char* e = getenv("SRX_RAYS_PER_OCTET")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) k = v; }   // experiments
+    const uint32_t rays_per_block = SRX_OCTETS_PER_BLOCK * (uint32_t)k;
+    uint32_t blocks = (a.n + rays_per_block - 1) / rays_per_block;
     blocks = (blocks + 7u) & ~7u;   // multiple of 8 so the XCD map covers every logical block exactly once
-    const size_t lds = (size_t)sc.stack_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
-                       (size_t)SRX_RAYS_PER_BLOCK * (3 * sizeof(float4) + sizeof(float));
-    if (mode == 0) hipLaunchKernelGGL(k_trace<0>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
-    else if (mode == 1) hipLaunchKernelGGL(k_trace<1>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
-    else hipLaunchKernelGGL(k_trace<2>, dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+    const size_t lds = trace_lds_bytes(sc.stack_depth, k);
+    if (k == 4) launch_k<4>(mode, blocks, lds, sc, a, stream);
+    else if (k == 2) launch_k<2>(mode, blocks, lds, sc, a, stream);
+    else launch_k<1>(mode, blocks, lds, sc, a, stream);
     return hipGetLastError();
 }
