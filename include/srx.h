@@ -223,6 +223,28 @@ int srx_process_rays(srx_renderer* r, const float* org3, const float* dir3, cons
 int srx_camera_rays(const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h, uint32_t pass_index,
                     uint64_t seed, float* dir3, uint64_t* keys);
 
+/* ---- output stage ---------------------------------------------------------------------------
+ * srx_post_process replaces the canvas conversion of SceneManager::refresh_canvas (SceneManager.h:1064-1072):
+ * ImageHandler::post_process_pixel (ImageProcessing.h:137-151: luminance-preserving gamma 1, view transform,
+ * luminance-preserving gamma 2.2, HSV round trip, clamp to [0, 1] x 255) on every pixel of the float4 framebuffer,
+ * then GUI::commit_pixel's float -> 8-bit store (GUI.h:104-107, truncation). d_rgba8 (4 B per pixel, alpha 255) and
+ * d_rgb_out (3 floats per pixel in [0, 255]) are device pointers; either may be NULL.
+ * The reference's view transform is an OpenColorIO processor built from a config file that is not in its repository
+ * (:9-11): SRX_TONEMAP_NONE leaves that step out (the parity path), SRX_TONEMAP_AGX_APPROX puts the public analytic
+ * AgX approximation in its place. */
+#define SRX_TONEMAP_NONE 0
+#define SRX_TONEMAP_AGX_APPROX 1
+int srx_post_process(const float* d_accum4, int32_t res_x, int32_t res_y, int32_t tonemap, uint8_t* d_rgba8,
+                     float* d_rgb_out);
+/* FileManager::writeRawFile / writeRaw (FileLoading.h:166-182): u32 res_x, u32 res_y, then res_y rows of res_x float3
+ * pixels (row 0 first) from the RGB of the float4 framebuffer (device pointer). */
+int srx_write_raw(const char* path, const float* d_accum4, int32_t res_x, int32_t res_y);
+/* FileManager::readRaw (FileLoading.h:183-199) into a host array of 3 floats per pixel; rgb NULL = header only. */
+int srx_read_raw(const char* path, float* rgb, uint64_t capacity_pixels, int32_t* res_x, int32_t* res_y);
+/* The canvas as an 8-bit RGBA PNG (the reference shows it in an SFML window, GUI.h:104-125; there is no file
+ * writer to mirror): stored deflate blocks, no compression library. d_rgba8 = device pointer from srx_post_process. */
+int srx_write_png(const char* path, const uint8_t* d_rgba8, int32_t res_x, int32_t res_y);
+
 #ifdef __cplusplus
 }
 #endif

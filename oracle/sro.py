@@ -252,3 +252,29 @@ class OracleNoise:
         out = np.ones(bx * by, np.float32)
         wrote = self.L.sro_noise_priorities(self.h, C.c_int32(seen), _p(out))
         return out, bool(wrote)
+
+
+# ---- output stage (oracle/sro_post.h) -----------------------------------------------------------------------
+def post_process(rgb, tonemap=0):
+    """ImageHandler::post_process_pixel over an array of linear RGB pixels: (float out in [0, 255], RGBA8)."""
+    a = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+    out = np.zeros_like(a)
+    u8 = np.zeros((len(a), 4), np.uint8)
+    lib().sro_post_process(_p(a), C.c_uint64(len(a)), C.c_int(tonemap), _p(out), _p(u8))
+    return out, u8
+
+
+def write_raw(path, rgb, res_x, res_y):
+    """FileManager::writeRaw (FileLoading.h:171-182): u32 resX, u32 resY, then rows of float3 pixels, row 0 first."""
+    a = np.ascontiguousarray(rgb, np.float32).reshape(res_y, res_x, 3)
+    with open(path, "wb") as fh:
+        fh.write(np.array([res_x, res_y], np.uint32).tobytes())
+        fh.write(a.tobytes())
+
+
+def read_raw(path):
+    """FileManager::readRaw (FileLoading.h:183-199): returns (rgb[res_y, res_x, 3], res_x, res_y)."""
+    with open(path, "rb") as fh:
+        rx, ry = (int(v) for v in np.frombuffer(fh.read(8), np.int32))
+        a = np.frombuffer(fh.read(rx * ry * 12), np.float32).reshape(ry, rx, 3).copy()
+    return a, rx, ry

@@ -5,6 +5,7 @@
 // links or loads this library. PARITY UNPINNED (see sro_math.h).
 #include "sro_shade.h"
 #include "sro_noise.h"
+#include "sro_post.h"
 #include <chrono>
 #include <thread>
 #include <atomic>
@@ -489,6 +490,18 @@ void sro_apply_rotation(const float* p3, const float* q4, uint32_t n, float* out
         Quat q; q.X = q4[4 * i]; q.Y = q4[4 * i + 1]; q.Z = q4[4 * i + 2]; q.W = q4[4 * i + 3];
         XYZ r = applyRotation(XYZ(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), q);
         out3[3 * i] = r.X; out3[3 * i + 1] = r.Y; out3[3 * i + 2] = r.Z;
+    }
+}
+
+// output stage (sro_post.h): rgb3 = n linear pixels; out3 = clamp(..)*255 as floats, out_rgba8 = what the canvas stores
+void sro_post_process(const float* rgb3, uint64_t n, int tonemap, float* out3, uint8_t* out_rgba8) {
+    for (uint64_t i = 0; i < n; i++) {
+        sro::RGB c = sro::post_process_pixel(sro::RGB{rgb3[3 * i], rgb3[3 * i + 1], rgb3[3 * i + 2]}, tonemap);
+        if (out3) { out3[3 * i] = c.X; out3[3 * i + 1] = c.Y; out3[3 * i + 2] = c.Z; }
+        if (out_rgba8) {
+            out_rgba8[4 * i] = sro::post_to_u8(c.X); out_rgba8[4 * i + 1] = sro::post_to_u8(c.Y);
+            out_rgba8[4 * i + 2] = sro::post_to_u8(c.Z); out_rgba8[4 * i + 3] = 255;
+        }
     }
 }
 
