@@ -51,6 +51,8 @@ def parse():
                     help="not the headline run: after the timed steps, run the adaptive-sampling loop (controller's minimum_samples = "
                          "MIN_SAMPLES, analysis every 4 visits) and report it under config.adaptive")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: exchange staged through the host)")
+    ap.add_argument("--share-of", type=int, default=1, metavar="N",
+                    help="rehearsal on one GPU: render only rank 0's share of an N-rank run (no exchange); value = this share's rays/s")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
@@ -168,7 +170,7 @@ def main():
     # this rank's share of the frame: tile rows (4 pixel rows) dealt round-robin over the ranks
     from raytracing_amd import tiles
     rect = (0, 0, W, H)
-    share = (tiles.TILE, rank, world)
+    share = (tiles.TILE, rank, world) if args.share_of <= 1 else (tiles.TILE, 0, args.share_of)
     accum = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
     aux = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
 

@@ -12,6 +12,7 @@
 // 8-byte count readback -> shadow kernel (adds lit direct-light contributions to the sample buffer).
 #include "srx_host.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -29,16 +30,25 @@ struct srx_renderer {
     uint64_t shadow_capacity = 0;
     GRay* rays = nullptr;
     GHit* hits = nullptr;
-    GShadow* shadow_q = nullptr;
-    DeviceCounts* d_counts = nullptr;
+    // Shadow rays of a batch are traced on a second stream while the next generation's closest-hit kernel runs on the
+    // first (they only share the atomically updated sample buffer and counters): two queues, used alternately, so the
+    // shade kernel never writes the queue a shadow kernel is still reading.
+    GShadow* shadow_q[2] = {nullptr, nullptr};
+    hipStream_t shadow_stream = nullptr;
+    hipEvent_t shadow_done[2] = {nullptr, nullptr};     // recorded on shadow_stream after the kernel that reads queue i
+    hipEvent_t shadow_t0[2] = {nullptr, nullptr};       // timing: start of that kernel
+    bool shadow_busy[2] = {false, false};               // an un-joined shadow kernel uses queue i
+    bool shadow_timed[2] = {false, false};
+    int shadow_flip = 0;
+    bool overlap_shadow = true;
+    DeviceCounts* d_counts = nullptr; // [3]: one per shadow queue, [2] for ray generation
     unsigned long long* d_counters = nullptr;
     float* sample3 = nullptr;         // per-pixel sample sums
     uint64_t sample_pixels = 0;
     hipStream_t stream = nullptr;
     DeviceCounts* h_counts = nullptr; // pinned
     bool timing = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool shadow_timing_pending = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // per-call accumulators
     uint64_t top = 0;
     srx_counters acc;
@@ -58,11 +68,17 @@ extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_
     chk(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
     chk(hipMalloc((void**)&r->rays, ray_capacity * sizeof(GRay)));
     chk(hipMalloc((void**)&r->hits, ray_capacity * sizeof(GHit)));
-    chk(hipMalloc((void**)&r->shadow_q, r->shadow_capacity * sizeof(GShadow)));
-    chk(hipMalloc((void**)&r->d_counts, sizeof(DeviceCounts)));
+    if (const char* e2 = getenv("SRX_SHADOW_STREAM")) r->overlap_shadow = atoi(e2) != 0;   // experiments: 0 = one stream
+    chk(hipStreamCreateWithFlags(&r->shadow_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        chk(hipMalloc((void**)&r->shadow_q[i], r->shadow_capacity * sizeof(GShadow)));
+        chk(hipEventCreate(&r->shadow_done[i]));
+        chk(hipEventCreate(&r->shadow_t0[i]));
+    }
+    chk(hipMalloc((void**)&r->d_counts, 3 * sizeof(DeviceCounts)));
     chk(hipMalloc((void**)&r->d_counters, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long)));
     chk(hipHostMalloc((void**)&r->h_counts, sizeof(DeviceCounts)));
-    for (int i = 0; i < 6; i++) chk(hipEventCreate(&r->ev[i]));
+    for (int i = 0; i < 4; i++) chk(hipEventCreate(&r->ev[i]));
     if (e != hipSuccess) {
         srx_set_error(std::string("srx_renderer_create: ") + hipGetErrorString(e));
         srx_renderer_destroy(r);
@@ -75,10 +91,17 @@ extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_
 extern "C" void srx_renderer_destroy(srx_renderer* r) {
     if (!r) return;
     if (r->stream) (void)hipStreamSynchronize(r->stream);
-    (void)hipFree(r->rays); (void)hipFree(r->hits); (void)hipFree(r->shadow_q);
+    if (r->shadow_stream) (void)hipStreamSynchronize(r->shadow_stream);
+    (void)hipFree(r->rays); (void)hipFree(r->hits);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(r->shadow_q[i]);
+        if (r->shadow_done[i]) (void)hipEventDestroy(r->shadow_done[i]);
+        if (r->shadow_t0[i]) (void)hipEventDestroy(r->shadow_t0[i]);
+    }
+    if (r->shadow_stream) (void)hipStreamDestroy(r->shadow_stream);
     (void)hipFree(r->d_counts); (void)hipFree(r->d_counters); (void)hipFree(r->sample3);
     if (r->h_counts) (void)hipHostFree(r->h_counts);
-    for (int i = 0; i < 6; i++) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
+    for (int i = 0; i < 4; i++) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -100,12 +123,28 @@ int ensure_sample_buffer(srx_renderer* r, uint64_t pixels) {
     return 0;
 }
 
-int collect_shadow_timing(srx_renderer* r) {
-    if (!r->shadow_timing_pending) return 0;
-    float ms = 0;
-    SRX_HIP(hipEventElapsedTime(&ms, r->ev[4], r->ev[5]));
-    r->acc.shadow_ms += ms;
-    r->shadow_timing_pending = false;
+// The shadow kernel that read queue i has to be over before the queue is written again / before the sample buffer is
+// read: the main stream waits for it on the device (no host wait), and its time is taken once it is known to be over.
+int retire_shadow(srx_renderer* r, int i, bool host_wait) {
+    if (!r->shadow_busy[i]) return 0;
+    if (host_wait) {
+        SRX_HIP(hipEventSynchronize(r->shadow_done[i]));
+        if (r->shadow_timed[i]) {
+            float ms = 0;
+            SRX_HIP(hipEventElapsedTime(&ms, r->shadow_t0[i], r->shadow_done[i]));
+            r->acc.shadow_ms += ms;
+            r->shadow_timed[i] = false;
+        }
+        r->shadow_busy[i] = false;
+    } else {
+        SRX_HIP(hipStreamWaitEvent(r->stream, r->shadow_done[i], 0));
+    }
+    return 0;
+}
+
+// every shadow kernel of this call is ordered before whatever the main stream does next (reads of the sample buffer)
+int join_shadows(srx_renderer* r) {
+    for (int i = 0; i < 2; i++) if (retire_shadow(r, i, false)) return 1;
     return 0;
 }
 
@@ -139,35 +178,44 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         SRX_HIP(srx_launch_trace(0, g, t, r->stream));
         if (r->timing) SRX_HIP(hipEventRecord(r->ev[1], r->stream));
 
-        // ---- shade + bounce (appends children at top, shadow rays into shadow_q)
-        SRX_HIP(hipMemsetAsync(r->d_counts, 0, sizeof(DeviceCounts), r->stream));
+        // ---- shade + bounce (appends children at top, shadow rays into shadow queue q)
+        const int q = r->shadow_flip;
+        if (retire_shadow(r, q, true)) return 1;       // the kernel that read queue q two batches ago (over long since)
+        DeviceCounts* const dc = r->d_counts + q;
+        SRX_HIP(hipMemsetAsync(dc, 0, sizeof(DeviceCounts), r->stream));
         ShadeArgs s;
         std::memset(&s, 0, sizeof(s));
         s.rays = r->rays + begin; s.hits = r->hits; s.n = (uint32_t)n; s.generation = gen;
-        s.out_rays = r->rays + r->top; s.out_count = &r->d_counts->out_count;
-        s.shadow_q = r->shadow_q; s.shadow_count = &r->d_counts->shadow_count;
+        s.out_rays = r->rays + r->top; s.out_count = &dc->out_count;
+        s.shadow_q = r->shadow_q[q]; s.shadow_count = &dc->shadow_count;
         s.sample3 = r->sample3; s.counters = r->d_counters; s.counter_slot_mask = CTR_SLOTS - 1; s.counter_slot_stride = CTR_COUNT;
         if (r->timing) SRX_HIP(hipEventRecord(r->ev[2], r->stream));
         SRX_HIP(srx_launch_shade(g, s, r->stream));
         if (r->timing) SRX_HIP(hipEventRecord(r->ev[3], r->stream));
-        SRX_HIP(hipMemcpyAsync(r->h_counts, r->d_counts, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
+        SRX_HIP(hipMemcpyAsync(r->h_counts, dc, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
         SRX_HIP(hipStreamSynchronize(r->stream));
-        if (collect_shadow_timing(r)) return 1;
         const uint64_t n_children = r->h_counts->out_count, n_shadow = r->h_counts->shadow_count;
         if (n_children > n * fan || r->top + n_children > r->capacity) SRX_FAIL("srx: internal error, child count exceeds the reserved slots");
-        if (n_shadow > r->shadow_capacity) SRX_FAIL("srx: internal error, shadow count exceeds the queue");
+        if (n_shadow > n * g.n_suns) SRX_FAIL("srx: internal error, shadow count exceeds the queue");
 
-        // ---- shadow rays of this batch: lit ones add their contribution to the sample buffer
+        // ---- shadow rays of this batch, on the second stream: the kernel runs next to the closest-hit kernel of the
+        // next generation (launched below on the main stream). The shade kernel that filled the queue is over (host
+        // synchronised above). Lit rays add their contribution to the sample buffer. (Launching it before the
+        // synchronisation, with a grid for the most rays there can be and the count read on the device, measured
+        // slower: 1250 against 1263 Mrays/s.)
         if (n_shadow) {
             TraceArgs sh;
             std::memset(&sh, 0, sizeof(sh));
-            sh.org = &r->shadow_q[0].ox; sh.org_stride = sizeof(GShadow) / 4;
+            sh.org = &r->shadow_q[q][0].ox; sh.org_stride = sizeof(GShadow) / 4;
             sh.n = (uint32_t)n_shadow;
-            sh.shadow_q = r->shadow_q; sh.sample3 = r->sample3;
+            sh.shadow_q = r->shadow_q[q]; sh.sample3 = r->sample3;
             sh.counters = r->d_counters + CTR_SNODES; sh.counter_slot_mask = CTR_SLOTS - 1; sh.counter_slot_stride = CTR_COUNT;
-            if (r->timing) SRX_HIP(hipEventRecord(r->ev[4], r->stream));
-            SRX_HIP(srx_launch_trace(2, g, sh, r->stream));
-            if (r->timing) SRX_HIP(hipEventRecord(r->ev[5], r->stream));
+            hipStream_t ss = r->overlap_shadow ? r->shadow_stream : r->stream;
+            if (r->timing) SRX_HIP(hipEventRecord(r->shadow_t0[q], ss));
+            SRX_HIP(srx_launch_trace(2, g, sh, ss));
+            SRX_HIP(hipEventRecord(r->shadow_done[q], ss));
+            r->shadow_busy[q] = true; r->shadow_timed[q] = r->timing;
+            r->shadow_flip ^= 1;
         }
         r->acc.rays_processed += n;
         r->acc.shadows_cast += n_shadow;
@@ -175,7 +223,6 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         if (n_shadow) r->acc.shadow_launches++;
         if (r->timing) {
             float ms = 0;
-            if (n_shadow) r->shadow_timing_pending = true;   // read at the next sync point (same stream => complete by then)
             SRX_HIP(hipEventElapsedTime(&ms, r->ev[0], r->ev[1])); r->acc.trace_ms += ms;
             SRX_HIP(hipEventElapsedTime(&ms, r->ev[2], r->ev[3])); r->acc.shade_ms += ms;
         }
@@ -192,8 +239,8 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
 }
 
 int begin_call(srx_renderer* r) {
+    for (int i = 0; i < 2; i++) if (retire_shadow(r, i, true)) return 1;   // left over from a call that failed half way
     std::memset(&r->acc, 0, sizeof(r->acc));
-    r->shadow_timing_pending = false;
     SRX_HIP(hipMemsetAsync(r->d_counters, 0, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long), r->stream));
     return 0;
 }
@@ -201,11 +248,12 @@ int begin_call(srx_renderer* r) {
 int end_call(srx_renderer* r, srx_counters* out) {
     static thread_local std::vector<unsigned long long> all;
     all.resize((size_t)CTR_SLOTS * CTR_COUNT);
+    if (join_shadows(r)) return 1;
     SRX_HIP(hipMemcpyAsync(all.data(), r->d_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
     SRX_HIP(hipStreamSynchronize(r->stream));
+    for (int i = 0; i < 2; i++) if (retire_shadow(r, i, true)) return 1;
     unsigned long long c[CTR_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int sl = 0; sl < CTR_SLOTS; sl++) for (int k = 0; k < CTR_COUNT; k++) c[k] += all[(size_t)sl * CTR_COUNT + k];
-    if (collect_shadow_timing(r)) return 1;
     r->acc.nodes = c[CTR_NODES]; r->acc.packets = c[CTR_PACKETS];
     r->acc.shadow_nodes = c[CTR_SNODES]; r->acc.shadow_packets = c[CTR_SPACKETS];
     r->acc.hits = c[CTR_HITS]; r->acc.texels = c[CTR_TEXELS]; r->acc.pdf_lookups = c[CTR_PDF];
@@ -250,6 +298,7 @@ extern "C" int srx_trace_pass_interleaved(srx_renderer* r, const srx_camera* cam
         r->top = n;
         if (process_segment(r, 0, 0, n)) return 1;
     }
+    if (join_shadows(r)) return 1;
     SRX_HIP(srx_launch_accumulate(camera->res_x, x0, w, rm, own_rows, pass_index, r->sample3, d_accum4, d_aux4, r->stream));
     return end_call(r, counters);
 }
@@ -285,15 +334,16 @@ extern "C" int srx_trace_pass_adaptive(srx_renderer* r, const srx_camera* camera
     for (int j = 0; j < own_rows; j += band_rows) {
         const int rows = std::min(band_rows, own_rows - j);
         // primaries of the blocks that fire, appended compactly; their number comes back with an 8-byte copy
-        SRX_HIP(hipMemsetAsync(r->d_counts, 0, sizeof(DeviceCounts), r->stream));
-        SRX_HIP(srx_launch_raygen_adaptive(cam, x0, w, rm, j, rows, a, r->rays, &r->d_counts->out_count, r->stream));
-        SRX_HIP(hipMemcpyAsync(r->h_counts, r->d_counts, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
+        SRX_HIP(hipMemsetAsync(r->d_counts + 2, 0, sizeof(DeviceCounts), r->stream));
+        SRX_HIP(srx_launch_raygen_adaptive(cam, x0, w, rm, j, rows, a, r->rays, &r->d_counts[2].out_count, r->stream));
+        SRX_HIP(hipMemcpyAsync(r->h_counts, r->d_counts + 2, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
         SRX_HIP(hipStreamSynchronize(r->stream));
         const uint64_t n = r->h_counts->out_count;
         if (n > (uint64_t)rows * w) SRX_FAIL("srx: internal error, more primaries than pixels");
         r->top = n;
         if (n && process_segment(r, 0, 0, n)) return 1;
     }
+    if (join_shadows(r)) return 1;
     SRX_HIP(srx_launch_accumulate_adaptive(camera->res_x, x0, w, rm, own_rows, a, r->sample3, d_accum4, d_aux4, r->stream));
     return end_call(r, counters);
 }
@@ -326,7 +376,7 @@ extern "C" int srx_process_rays(srx_renderer* r, const float* org3, const float*
             if (srx_launch_pack_rays(d_o + 3 * b, d_d + 3 * b, d_k + b, m, r->rays, r->stream) != hipSuccess) { srx_set_error("srx_process_rays: pack launch failed"); rc = 1; break; }
             // pixel index of ray i is i within the chunk: shift by the chunk base afterwards
             r->top = m;
-            if (process_segment(r, generation, 0, m)) { rc = 1; break; }
+            if (process_segment(r, generation, 0, m) || join_shadows(r)) { rc = 1; break; }
             if (hipMemcpyAsync(radiance3 + 3 * b, r->sample3, (size_t)m * 12, hipMemcpyDeviceToHost, r->stream) != hipSuccess ||
                 hipMemsetAsync(r->sample3, 0, (size_t)m * 12, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess) {
                 srx_set_error("srx_process_rays: readback failed"); rc = 1; break;

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     // ray j of this octet; the block's rays are contiguous in the queue
     const uint32_t ray0 = lblock * SRX_RAYS_PER_BLOCK + oct;
+    const uint32_t n_rays = a.n;
     float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {o, d.x}, {d.yz, inv.xy}, {inv.z, fused}
     float* const s_pt = (float*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening
     // (LDS per wave = 64 B x stack depth + 1 792 B; 5 120 B is what 32 waves per CU can have)
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     bool fast;
     {
         const uint32_t myray = ray0 + (uint32_t)sub * SRX_OCTETS_PER_BLOCK;
-        const bool mine = sub < K && lblock < nblk && myray < a.n;
+        const bool mine = sub < K && lblock < nblk && myray < n_rays;
         f3 so, sd;
         if (mine) {
             const float* po = a.org + (size_t)myray * a.org_stride;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     }
     // rays of this octet that exist: indices grow with j, so they are j = 0 .. cnt-1
     int cnt = 0;
-    if (lblock < nblk && ray0 < a.n) cnt = (int)min((uint32_t)K, (a.n - ray0 + SRX_OCTETS_PER_BLOCK - 1) / SRX_OCTETS_PER_BLOCK);
+    if (lblock < nblk && ray0 < n_rays) cnt = (int)min((uint32_t)K, (n_rays - ray0 + SRX_OCTETS_PER_BLOCK - 1) / SRX_OCTETS_PER_BLOCK);
     int cur = 0;
     uint32_t ray = ray0;
     const bool live = cnt > 0;
