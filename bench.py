@@ -51,6 +51,9 @@ def parse():
                     help="not the headline run: after the timed steps, run the adaptive-sampling loop (controller's minimum_samples = "
                          "MIN_SAMPLES, analysis every 4 visits) and report it under config.adaptive")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: exchange staged through the host)")
+    ap.add_argument("--passes-per-call", type=int, default=0, metavar="B",
+                    help="sample passes (steps) that share their kernel launches; 0 = the number of ranks, so a rank's launches stay as "
+                         "large as the single GPU's (every step's work is still done inside the timed region)")
     ap.add_argument("--share-of", type=int, default=1, metavar="N",
                     help="rehearsal on one GPU: render only rank 0's share of an N-rank run (no exchange); value = this share's rays/s")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -179,13 +182,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for p in range(args.warmup):
-        RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share)
+    # steps = sample passes; B of them travel through the same kernel launches (same samples as one call per pass)
+    B = args.passes_per_call if args.passes_per_call > 0 else max(world, args.share_of)
+    B = max(1, min(B, ((1 << 24) - 1) // (W * H)))
+    for p in range(0, args.warmup, B):
+        RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share, n_passes=min(B, args.warmup - p))
     barrier()
     t0 = time.perf_counter()
     tot = {}
-    for p in range(args.warmup, args.warmup + args.steps):
-        c = RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share)
+    for p in range(args.warmup, args.warmup + args.steps, B):
+        c = RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share,
+                          n_passes=min(B, args.warmup + args.steps - p))
         for k, v in c.items():
             tot[k] = tot.get(k, 0) + v
     if world > 1:
@@ -247,6 +254,7 @@ def main():
                 "ray_capacity": args.ray_capacity,
                 "scene_package_s": t_pack,
                 "stack_depth": RE.stack_bound(),
+                "passes_per_call": B,
             },
             "roofline": {
                 "kernel": "k_trace<0> (closest-hit traversal)",

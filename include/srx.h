@@ -176,6 +176,14 @@ int srx_trace_pass(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_
 int srx_trace_pass_interleaved(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
                                int32_t group_rows, int32_t part, int32_t nparts, uint32_t pass_index, uint64_t seed,
                                float* d_accum4, float* d_aux4, srx_counters* counters);
+/* n_passes consecutive sample passes (pass_index .. pass_index + n_passes - 1) of the same rectangle and share in ONE
+ * call: the rays of all of them travel through the same kernel launches (what the reference gets from keeping every
+ * core busy on its own block, SceneManager.h:137-165, a GPU gets from launches that are large enough: a 1/8 share of
+ * a 1080p frame runs 12 % below the full frame's rate with one pass per call). Same result as n_passes calls of
+ * srx_trace_pass_interleaved, sample for sample; pixels x n_passes < 2^24. */
+int srx_trace_passes_interleaved(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                                 int32_t group_rows, int32_t part, int32_t nparts, uint32_t pass_index, int32_t n_passes,
+                                 uint64_t seed, float* d_accum4, float* d_aux4, srx_counters* counters);
 
 /* ---- adaptive sampling: replaces SceneManager::analyze_noise (SceneManager.h:526-667), the
  * priority half of SceneManager::balance_threads (:668-692) and the per-block visit rule of

@@ -50,7 +50,8 @@ __host__ __device__ inline int srx_row_of(const GRows& m, int j) {
 }
 // rays for local rows [j0, j0 + rows) x columns [x0, x0 + w)
 extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, uint32_t pass_index,
-                                        uint64_t seed, GRay* rays, float* dir3, unsigned long long* keys, hipStream_t stream);
+                                        uint64_t seed, uint32_t slot_base, GRay* rays, float* dir3, unsigned long long* keys,
+                                        hipStream_t stream);
 // Adaptive visit (SceneManager.h:193-237): rays only for the pixels of blocks that fire; appended compactly at rays[*count].
 struct AdaptiveArgs {
     const float* block_priority;     // per 4x4 block, NULL = all 1
@@ -65,5 +66,5 @@ extern "C" hipError_t srx_launch_accumulate_adaptive(int res_x, int x0, int w, G
                                                      float* accum4, float* aux4, hipStream_t stream);
 extern "C" hipError_t srx_launch_pack_rays(const float* org3, const float* dir3, const unsigned long long* keys, uint32_t n,
                                            GRay* rays, hipStream_t stream);
-extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int w, GRows rows_map, int rows, uint32_t pass_index, float* sample3,
-                                            float* accum4, float* aux4, hipStream_t stream);
+extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int w, GRows rows_map, int rows, uint32_t pass_index, int n_passes,
+                                            uint32_t slot_stride, float* sample3, float* accum4, float* aux4, hipStream_t stream);

@@ -267,14 +267,21 @@ int end_call(srx_renderer* r, srx_counters* out) {
 extern "C" int srx_trace_pass_interleaved(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
                                           int32_t group_rows, int32_t part, int32_t nparts, uint32_t pass_index, uint64_t seed,
                                           float* d_accum4, float* d_aux4, srx_counters* counters) {
+    return srx_trace_passes_interleaved(r, camera, x0, y0, w, h, group_rows, part, nparts, pass_index, 1, seed, d_accum4, d_aux4, counters);
+}
+
+extern "C" int srx_trace_passes_interleaved(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                                            int32_t group_rows, int32_t part, int32_t nparts, uint32_t pass_index, int32_t n_passes,
+                                            uint64_t seed, float* d_accum4, float* d_aux4, srx_counters* counters) {
     if (!r || !camera || !d_accum4) SRX_FAIL("srx_trace_pass: null argument");
+    if (n_passes <= 0) SRX_FAIL("srx_trace_passes_interleaved: n_passes must be at least 1");
     if (camera->res_x <= 0 || camera->res_y <= 0 || camera->subdiv <= 0) SRX_FAIL("srx_trace_pass: bad camera");
     if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > camera->res_x || y0 + h > camera->res_y)
         SRX_FAIL("srx_trace_pass: rectangle outside the camera resolution");
     if (group_rows <= 0 || nparts <= 0 || part < 0 || part >= nparts) SRX_FAIL("srx_trace_pass_interleaved: bad row interleave (group_rows, part, nparts)");
     const uint64_t npix = (uint64_t)camera->res_x * camera->res_y;
-    if (npix > 0x00FFFFFFull) SRX_FAIL("srx_trace_pass: more than 2^24-1 pixels is not supported");
-    if (ensure_sample_buffer(r, npix)) return 1;
+    if (npix * (uint64_t)n_passes > 0x00FFFFFFull) SRX_FAIL("srx_trace_pass: more than 2^24-1 pixels x passes in flight is not supported");
+    if (ensure_sample_buffer(r, npix * (uint64_t)n_passes)) return 1;
     if (begin_call(r)) return 1;
     static_assert(sizeof(GCamera) == sizeof(srx_camera), "camera layout");
     GCamera cam;
@@ -289,17 +296,20 @@ extern "C" int srx_trace_pass_interleaved(srx_renderer* r, const srx_camera* cam
     const GScene& g = r->scene->g;
     const uint64_t fan0 = (uint64_t)std::max(1, g.bounce_count[0]);
     uint64_t band_rays = r->capacity / (1 + (g.max_generations > 0 ? fan0 : 0));
-    if (band_rays < (uint64_t)w) SRX_FAIL("srx_trace_pass: ray_capacity too small for one pixel row and its first bounce");
-    const int band_rows = (int)std::min<uint64_t>((uint64_t)own_rows, band_rays / (uint64_t)w);
+    if (band_rays < (uint64_t)w * (uint64_t)n_passes) SRX_FAIL("srx_trace_pass: ray_capacity too small for one pixel row of every pass and its first bounce");
+    const int band_rows = (int)std::min<uint64_t>((uint64_t)own_rows, band_rays / ((uint64_t)w * (uint64_t)n_passes));
     for (int j = 0; j < own_rows; j += band_rows) {
         const int rows = std::min(band_rows, own_rows - j);
-        const uint64_t n = (uint64_t)rows * w;
-        SRX_HIP(srx_launch_raygen(cam, x0, w, rm, j, rows, pass_index, seed, r->rays, nullptr, nullptr, r->stream));
-        r->top = n;
-        if (process_segment(r, 0, 0, n)) return 1;
+        const uint64_t n1 = (uint64_t)rows * w;
+        // the primaries of all the passes of this band share the launches of every generation
+        for (int p = 0; p < n_passes; p++)
+            SRX_HIP(srx_launch_raygen(cam, x0, w, rm, j, rows, pass_index + (uint32_t)p, seed, (uint32_t)((uint64_t)p * npix), r->rays + (uint64_t)p * n1,
+                                      nullptr, nullptr, r->stream));
+        r->top = n1 * (uint64_t)n_passes;
+        if (process_segment(r, 0, 0, n1 * (uint64_t)n_passes)) return 1;
     }
     if (join_shadows(r)) return 1;
-    SRX_HIP(srx_launch_accumulate(camera->res_x, x0, w, rm, own_rows, pass_index, r->sample3, d_accum4, d_aux4, r->stream));
+    SRX_HIP(srx_launch_accumulate(camera->res_x, x0, w, rm, own_rows, pass_index, n_passes, (uint32_t)npix, r->sample3, d_accum4, d_aux4, r->stream));
     return end_call(r, counters);
 }
 
@@ -400,7 +410,7 @@ extern "C" int srx_camera_rays(const srx_camera* camera, int32_t x0, int32_t y0,
     SRX_HIP(hipMalloc((void**)&d_d, n * 12)); SRX_HIP(hipMalloc((void**)&d_k, n * 8));
     GRows rm;
     rm.y0 = y0; rm.group = h; rm.nparts = 1; rm.part = 0;
-    hipError_t e = srx_launch_raygen(cam, x0, w, rm, 0, h, pass_index, seed, nullptr, d_d, d_k, 0);
+    hipError_t e = srx_launch_raygen(cam, x0, w, rm, 0, h, pass_index, seed, 0, nullptr, d_d, d_k, 0);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(dir3, d_d, n * 12, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(keys, d_k, n * 8, hipMemcpyDeviceToHost);

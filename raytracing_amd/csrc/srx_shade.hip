@@ -432,8 +432,9 @@ __device__ __forceinline__ f3 camera_slope(const GCamera& c, int px, int py, uin
     return apply_rotation(slope, c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 }
 
+// slot_base: added to the pixel index a ray carries (the slot of its sample sums) when several passes are in flight
 __global__ __launch_bounds__(256) void k_raygen(GCamera c, int x0, int w, GRows rm, int j0, int rows, uint32_t pass_index, uint64_t seed,
-                                               GRay* rays, float* dir3, unsigned long long* keys) {
+                                               uint32_t slot_base, GRay* rays, float* dir3, unsigned long long* keys) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint32_t)(w * rows)) return;
     const int px = x0 + (int)(idx % (uint32_t)w), py = srx_row_of(rm, j0 + (int)(idx / (uint32_t)w));
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256) void k_raygen(GCamera c, int x0, int w, GRows 
         r.ox = c.pos[0]; r.oy = c.pos[1]; r.oz = c.pos[2];
         r.dx = d.x; r.dy = d.y; r.dz = d.z;
         r.cr = 1.0f; r.cg = 1.0f; r.cb = 1.0f;
-        r.pixel = pixel;
+        r.pixel = slot_base + pixel;
         r.key_lo = (uint32_t)g.s; r.key_hi = (uint32_t)(g.s >> 32);
         rays[idx] = r;
     }
@@ -551,15 +552,20 @@ __global__ __launch_bounds__(256) void k_pack_rays(const float* org3, const floa
 // ---------------------------------------------------------------- accumulation (SceneManager.h:220-233)
 // accum4/aux4: float4 per pixel = (running mean rgb, sample count). A non-finite sample is skipped
 // (the reference redraws it); the aux buffer takes the odd passes (add_aux toggles per pass).
-__global__ __launch_bounds__(256) void k_accumulate(int res_x, int x0, int w, GRows rm, int rows, uint32_t pass_index, float* sample3,
-                                                   float4* accum4, float4* aux4) {
+// n_passes samples per pixel (passes pass_index .. pass_index + n_passes - 1, sums at slot p * slot_stride + pixel) are
+// folded in one after the other, exactly as n_passes calls with one pass each would
+__global__ __launch_bounds__(256) void k_accumulate(int res_x, int x0, int w, GRows rm, int rows, uint32_t pass_index0, int n_passes,
+                                                   uint32_t slot_stride, float* sample3, float4* accum4, float4* aux4) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint32_t)(w * rows)) return;
     const int px = x0 + (int)(idx % (uint32_t)w), py = srx_row_of(rm, (int)(idx / (uint32_t)w));
     const size_t pixel = (size_t)py * res_x + px;
-    const f3 res(sample3[3 * pixel], sample3[3 * pixel + 1], sample3[3 * pixel + 2]);
-    sample3[3 * pixel] = 0.0f; sample3[3 * pixel + 1] = 0.0f; sample3[3 * pixel + 2] = 0.0f;
-    if (!(well_defined(res.x) && well_defined(res.y) && well_defined(res.z))) return;
+  for (int p = 0; p < n_passes; p++) {
+    const uint32_t pass_index = pass_index0 + (uint32_t)p;
+    const size_t slot = (size_t)p * slot_stride + pixel;
+    const f3 res(sample3[3 * slot], sample3[3 * slot + 1], sample3[3 * slot + 2]);
+    sample3[3 * slot] = 0.0f; sample3[3 * slot + 1] = 0.0f; sample3[3 * slot + 2] = 0.0f;
+    if (!(well_defined(res.x) && well_defined(res.y) && well_defined(res.z))) continue;
     {
         float4 o = accum4[pixel];
         const int n = (int)o.w;
@@ -576,6 +582,7 @@ __global__ __launch_bounds__(256) void k_accumulate(int res_x, int x0, int w, GR
         cur = cur + (float)(1.0 / (n + 1)) * res;
         aux4[pixel] = make_float4(cur.x, cur.y, cur.z, (float)(n + 1));
     }
+  }
 }
 
 // ---------------------------------------------------------------- launchers
@@ -585,10 +592,12 @@ extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hip
     return hipGetLastError();
 }
 extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, uint32_t pass_index,
-                                        uint64_t seed, GRay* rays, float* dir3, unsigned long long* keys, hipStream_t stream) {
+                                        uint64_t seed, uint32_t slot_base, GRay* rays, float* dir3, unsigned long long* keys,
+                                        hipStream_t stream) {
     const uint32_t n = (uint32_t)(w * rows);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, stream, c, x0, w, rows_map, j0, rows, pass_index, seed, rays, dir3, keys);
+    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, stream, c, x0, w, rows_map, j0, rows, pass_index, seed, slot_base, rays,
+                       dir3, keys);
     return hipGetLastError();
 }
 extern "C" hipError_t srx_launch_raygen_adaptive(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, AdaptiveArgs a,
@@ -612,11 +621,11 @@ extern "C" hipError_t srx_launch_pack_rays(const float* org3, const float* dir3,
     hipLaunchKernelGGL(k_pack_rays, dim3((n + 255) / 256), dim3(256), 0, stream, org3, dir3, keys, n, rays);
     return hipGetLastError();
 }
-extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int w, GRows rows_map, int rows, uint32_t pass_index, float* sample3,
-                                            float* accum4, float* aux4, hipStream_t stream) {
+extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int w, GRows rows_map, int rows, uint32_t pass_index, int n_passes,
+                                            uint32_t slot_stride, float* sample3, float* accum4, float* aux4, hipStream_t stream) {
     const uint32_t n = (uint32_t)(w * rows);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, stream, res_x, x0, w, rows_map, rows, pass_index, sample3,
-                       (float4*)accum4, (float4*)aux4);
+    hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, stream, res_x, x0, w, rows_map, rows, pass_index, n_passes,
+                       slot_stride, sample3, (float4*)accum4, (float4*)aux4);
     return hipGetLastError();
 }

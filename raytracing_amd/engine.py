@@ -211,9 +211,10 @@ class RayEngine:
                                              _dev_ptr(aux4), C.byref(ctr)), "srx_trace_pass_adaptive")
         return ctr.as_dict()
 
-    def trace_pass(self, camera, rect, pass_index, seed, accum4, aux4=None, ray_capacity=1 << 22, interleave=None):
-        """One sample pass of `RenderThread::process_iteratively` (SceneManager.h:193-237) over a pixel
-        rectangle; accum4/aux4 are device float4 framebuffers (torch tensors or raw addresses).
+    def trace_pass(self, camera, rect, pass_index, seed, accum4, aux4=None, ray_capacity=1 << 22, interleave=None, n_passes=1):
+        """`n_passes` consecutive sample passes (default one) of `RenderThread::process_iteratively` (SceneManager.h:193-237)
+        over a pixel rectangle; accum4/aux4 are device float4 framebuffers (torch tensors or raw addresses). Several
+        passes in one call share their kernel launches and give the same samples as one call per pass.
 
         `interleave=(group_rows, part, nparts)` renders only this caller's share of the rows: row groups
         part, part + nparts, ... (the reference's interleaved block assignment, SceneManager.h:441-459)."""
@@ -221,10 +222,10 @@ class RayEngine:
         x0, y0, w, h = rect
         group, part, nparts = interleave if interleave is not None else (max(1, h), 0, 1)
         ctr = SrxCounters()
-        check(self.L.srx_trace_pass_interleaved(self.renderer(ray_capacity), _p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w),
-                                                C.c_int32(h), C.c_int32(group), C.c_int32(part), C.c_int32(nparts),
-                                                C.c_uint32(pass_index), C.c_uint64(seed), _dev_ptr(accum4), _dev_ptr(aux4),
-                                                C.byref(ctr)), "srx_trace_pass_interleaved")
+        check(self.L.srx_trace_passes_interleaved(self.renderer(ray_capacity), _p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w),
+                                                  C.c_int32(h), C.c_int32(group), C.c_int32(part), C.c_int32(nparts),
+                                                  C.c_uint32(pass_index), C.c_int32(n_passes), C.c_uint64(seed), _dev_ptr(accum4),
+                                                  _dev_ptr(aux4), C.byref(ctr)), "srx_trace_passes_interleaved")
         return ctr.as_dict()
 
 

@@ -170,6 +170,39 @@ def test_interleaved_parts_compose_to_the_full_pass(loaded):
     assert np.allclose(a[:, :3], b[:, :3], rtol=1e-4, atol=1e-6)
 
 
+def test_several_passes_in_one_call_equal_one_call_per_pass(loaded):
+    """srx_trace_passes_interleaved: 3 passes in one call (their rays share every launch) = 3 calls of one pass: same
+    sample counts in both buffers, same rays and traversal counters, radiance equal up to float-atomic summation
+    order; a share of interleaved rows behaves the same; too many passes for the 24-bit sample slots fail loudly."""
+    import torch
+    from raytracing_amd import _lib
+    name, desc, RE, S = loaded
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    for interleave in (None, (4, 1, 2)):
+        one = [torch.zeros((h * w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        many = [torch.zeros((h * w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        tot = {}
+        for p in range(1, 4):
+            c = RE.trace_pass(cam, (0, 0, w, h), p, 77, one[0], one[1], interleave=interleave)
+            for k in ("rays_processed", "shadows_cast", "nodes", "packets", "hits"):
+                tot[k] = tot.get(k, 0) + int(c[k])
+        c3 = RE.trace_pass(cam, (0, 0, w, h), 1, 77, many[0], many[1], interleave=interleave, n_passes=3)
+        torch.cuda.synchronize()
+        for k, v in tot.items():
+            assert int(c3[k]) == v, k
+        assert int(c3["trace_launches"]) < 3 * int(c["trace_launches"])
+        for a, b in zip(one, many):
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+            assert np.array_equal(a[:, 3], b[:, 3])
+            assert np.allclose(a[:, :3], b[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
+        assert float(many[1][:, 3].max()) == 2.0            # aux took passes 1 and 3
+    with pytest.raises(_lib.SrxError):
+        RE.trace_pass(cam, (0, 0, w, h), 0, 77, many[0], many[1], n_passes=(1 << 24) // (w * h) + 1)
+    with pytest.raises(_lib.SrxError):
+        RE.trace_pass(cam, (0, 0, w, h), 0, 77, many[0], many[1], n_passes=0)
+
+
 def test_converged_image_matches_reference_rng_estimator(tables):
     """Property test at image level: the GPU (keyed per-ray streams, throughput carried down the path, float atomics)
     and the oracle in REFERENCE mode (one sequential xoshiro stream, recursion multiplying on the way back,
