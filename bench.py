@@ -187,6 +187,12 @@ def main():
     B = max(1, min(B, ((1 << 24) - 1) // (W * H)))
     for p in range(0, args.warmup, B):
         RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share, n_passes=min(B, args.warmup - p))
+    if world > 1:
+        # warm-up of the two exchanges as well (communicator set-up, index tensors); they only fill in the other ranks' rows
+        sums, mins = tiles.rows_noise_stats(accum, aux, H, W, tiles.interleaved_rows(rank, world, H))
+        tiles.allreduce_noise_stats(sums, mins)
+        tiles.gather_framebuffer_interleaved(accum, H, W)
+        tiles.gather_framebuffer_interleaved(aux, H, W)
     barrier()
     t0 = time.perf_counter()
     tot = {}

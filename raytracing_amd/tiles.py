@@ -89,10 +89,21 @@ def gather_framebuffer_interleaved(buf: torch.Tensor, height: int, width: int, t
     return _host_staged(_gather_interleaved, buf, height, width, tile)
 
 
+_OWNED = {}
+
+
+def _owned_rows(world, height, tile, device):
+    """Row indices of every rank on `device`, built once per layout (the gather sits inside timed regions)."""
+    key = (world, height, tile, str(device))
+    if key not in _OWNED:
+        _OWNED[key] = [interleaved_rows(r, world, height, tile).to(device) for r in range(world)]
+    return _OWNED[key]
+
+
 def _gather_interleaved(buf, height, width, tile):
     world, rank = dist.get_world_size(), dist.get_rank()
     view = buf.view(height, -1)
-    owned = [interleaved_rows(r, world, height, tile).to(buf.device) for r in range(world)]
+    owned = _owned_rows(world, height, tile, buf.device)
     most = max(len(o) for o in owned)
     mine = torch.zeros((most, view.shape[1]), dtype=buf.dtype, device=buf.device)
     mine[: len(owned[rank])] = view[owned[rank]]
