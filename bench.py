@@ -271,6 +271,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.tris, args.res, args.scene) if world == 1 else None,
                 "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, bytes per launch)",
+                "concurrency": ("shadow kernels run on a second stream beside this kernel: avg_launch_ms includes the time they share "
+                                "the chip (SRX_SHADOW_STREAM=0 times it alone: profiles/r01_kernel_stats_single_stream.csv)")
+                               if os.environ.get("SRX_SHADOW_STREAM", "1") != "0" else "one stream",
                 "launches": int(launches),
                 "avg_launch_ms": trace_ms / launches,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
