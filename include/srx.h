@@ -253,6 +253,19 @@ int srx_read_raw(const char* path, float* rgb, uint64_t capacity_pixels, int32_t
  * writer to mirror): stored deflate blocks, no compression library. d_rgba8 = device pointer from srx_post_process. */
 int srx_write_png(const char* path, const uint8_t* d_rgba8, int32_t res_x, int32_t res_y);
 
+/* ---- scene ingestion: replaces FileManager::loadGLTFFile / parseGLTFData (FileLoading.h:200-224,
+ * 438-782) and the flattening the reference applies before Scene::package (Object::fetchData, Primitives.h:423-434):
+ * a binary glTF (.glb) becomes world-space srx_tri records (in the order Scene::package would collect them), the
+ * material table (the file's materials + the reference's "SR default material" last), textures as the reference
+ * stores them (Texture.h, 3 bytes per texel; embedded 8-bit PNG images only), sun lights and the first camera
+ * (res_x, res_y, subdiv are left 0 for the caller). Axis conventions, factors and quirks: see csrc/srx_gltf.cpp.
+ * Host-only; the arrays belong to the handle. */
+typedef struct srx_gltf srx_gltf;
+int srx_gltf_load(const char* path, srx_gltf** out);
+void srx_gltf_destroy(srx_gltf* g);
+int srx_gltf_get(const srx_gltf* g, const srx_tri** tris, uint32_t* n_tris, const srx_material** materials, uint32_t* n_materials,
+                 const srx_texture** textures, uint32_t* n_textures, const srx_sun** suns, uint32_t* n_suns, srx_camera* camera);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,4 +33,26 @@ void ref_misc(const float* a3, const float* b3, float c, uint32_t n, float* fmin
         slope3[3 * i] = s.X; slope3[3 * i + 1] = s.Y; slope3[3 * i + 2] = s.Z;
     }
 }
+// scene ingestion (oracle/sro_gltf.py, csrc/srx_gltf.cpp): the swizzle constructors the loader feeds glTF node data
+// through (XYZ.cpp:97,115-121,613) and Quat::multiply (XYZ.cpp:626-633) as Transformation::stack uses it
+void ref_swizzles(const double* attr4, uint32_t n, float* pos3, float* scale3, float* rot4, float* vswz3) {
+    std::vector<char> swizzle = {0, -2, 1}, rot_swizzle = {0, -2, 1, 3}, scale_swizzle = {0, 2, 1};   // FileLoading.h:450-452
+    for (uint32_t i = 0; i < n; i++) {
+        std::vector<double> a4(attr4 + 4 * i, attr4 + 4 * i + 4), a3(attr4 + 4 * i, attr4 + 4 * i + 3);
+        XYZ p(a3, swizzle), sc(a3, scale_swizzle);
+        Quat q(a4, rot_swizzle);
+        XYZ v = XYZ((float)a3[0], (float)a3[1], (float)a3[2]).swizzle(swizzle);
+        pos3[3 * i] = p.X; pos3[3 * i + 1] = p.Y; pos3[3 * i + 2] = p.Z;
+        scale3[3 * i] = sc.X; scale3[3 * i + 1] = sc.Y; scale3[3 * i + 2] = sc.Z;
+        rot4[4 * i] = q.X; rot4[4 * i + 1] = q.Y; rot4[4 * i + 2] = q.Z; rot4[4 * i + 3] = q.W;
+        vswz3[3 * i] = v.X; vswz3[3 * i + 1] = v.Y; vswz3[3 * i + 2] = v.Z;
+    }
+}
+void ref_quat_multiply(const float* a4, const float* b4, uint32_t n, float* out4) {
+    for (uint32_t i = 0; i < n; i++) {
+        Quat a(a4[4 * i], a4[4 * i + 1], a4[4 * i + 2], a4[4 * i + 3]), b(b4[4 * i], b4[4 * i + 1], b4[4 * i + 2], b4[4 * i + 3]);
+        Quat r = Quat::multiply(a, b);
+        out4[4 * i] = r.X; out4[4 * i + 1] = r.Y; out4[4 * i + 2] = r.Z; out4[4 * i + 3] = r.W;
+    }
+}
 }

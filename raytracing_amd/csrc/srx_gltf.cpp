@@ -1,0 +1,808 @@
+// raytracing_amd/csrc/srx_gltf.cpp — scene ingestion: binary glTF (.glb) -> the flat arrays the
+// packager and srx_scene_create take. Host code only. Replaces FileManager::loadGLTFFile / parseGLTFData
+// (FileLoading.h:200-224, 438-782) together with what the reference does to the result before Scene::package sees it:
+// Tri construction (Primitives.h:237-252), Object::fetchData / Packers::transformT flattening (Primitives.h:347-373,
+// 423-434) with Object::compile_scale (:462-471) and Transformation::collpase (Transformation.h:28-57).
+//
+// The reference reads the file with tinygltf (a third-party header, not restated: this file has its own JSON and GLB
+// reader) and decodes embedded images with stb_image; here images must be 8-bit non-interlaced PNG (own inflate), any
+// other image fails loudly. Reference behaviour kept on purpose (each is what the author's scenes were exported for):
+//  * axis swizzle (x, -z, y) for positions, normals and translations, (x, z, y) for scales, (x, -z, y, w) for
+//    rotations (:450-452); uv -> (u, 1 - v) (:658-660); emissive x 25 (:473); sun emission = color * intensity / 50000
+//    (:731), sun direction = (0, -1, 0) rotated (:726-727);
+//  * only nodes that carry a camera, a mesh or a light exist (:687-742): transforms of plain group nodes are ignored;
+//  * an accessor index of 0 for TEXCOORD_n / NORMAL means "absent" (:614,620: std::map::operator[] yields 0);
+//  * a child's scale is child^2 * parent (Object::compile_scale multiplies its argument in twice);
+//  * normals are rotated, never inverse-transpose scaled (Packers::transformT);
+//  * KHR_materials_specular without specularColorFactor -> specular 0; without the extension -> 1 (:535-552);
+//    IOR 1.5 / transmission 0 without their extensions (:553-574); a last "SR default material" (:579-587);
+//  * textures: the loaders skip the first texel and read one past the end (Texture.h:41,57; quirk Q9; the last texel
+//    is taken from a zero pad here), base colour goes through the luminance gamma 2.2 (converter_xyz_sRGB, :361-363)
+//    and back to 8 bits by truncation (Texture.h:126-131), metallic / roughness are channels 2 / 1 re-quantised the
+//    same way (Texture.h:214-226), normal maps are normalize((c*2-1)*(s,s,1)) stored as v*127+128 (Texture.h:51-67,
+//    116-125); metallicFactor scales the first width*height BYTES of the metallic texture (:505-511).
+// Differences: accessors honour byteOffset / byteStride as the glTF specification says (the reference copies the whole
+// bufferView, :252-263 — identical for tightly packed, one-accessor views); children that are not mesh nodes are
+// ignored (the reference indexes its object list with them, :743-755, undefined behaviour); no camera -> error.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/srx.h"
+
+void srx_set_error(const std::string& s);
+
+namespace {
+
+struct Fail { std::string msg; };
+[[noreturn]] void fail(const std::string& m) { throw Fail{m}; }
+
+// ---------------------------------------------------------------- JSON
+struct JV {
+    enum T { NUL, BOOL, NUM, STR, ARR, OBJ } t = NUL;
+    double num = 0; bool b = false; std::string s;
+    std::vector<JV> a;
+    std::vector<std::pair<std::string, JV>> o;
+    const JV* get(const char* k) const {
+        if (t != OBJ) return nullptr;
+        for (auto& kv : o) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+    bool has(const char* k) const { return get(k) != nullptr; }
+    double number(const char* k, double def) const { const JV* v = get(k); return (v && v->t == NUM) ? v->num : def; }
+    int integer(const char* k, int def) const { const JV* v = get(k); return (v && v->t == NUM) ? (int)v->num : def; }
+    std::string str(const char* k) const { const JV* v = get(k); return (v && v->t == STR) ? v->s : std::string(); }
+    size_t size() const { return t == ARR ? a.size() : 0; }
+    const JV& at(size_t i) const { static const JV nul; return (t == ARR && i < a.size()) ? a[i] : nul; }
+    double as_double() const { return t == NUM ? num : 0.0; }      // tinygltf Value::GetNumberAsDouble on a non-number: 0
+};
+
+struct JParser {
+    const char* p; const char* e;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; }
+    JV parse() { ws(); JV v = value(0); ws(); return v; }
+    JV value(int depth) {
+        if (depth > 200) fail("glTF JSON nested too deep");
+        ws();
+        if (p >= e) fail("glTF JSON ends early");
+        JV v;
+        if (*p == '{') {
+            v.t = JV::OBJ; p++; ws();
+            if (p < e && *p == '}') { p++; return v; }
+            for (;;) {
+                ws();
+                if (p >= e || *p != '"') fail("glTF JSON: expected a key");
+                std::string k = string();
+                ws();
+                if (p >= e || *p != ':') fail("glTF JSON: expected ':'");
+                p++;
+                v.o.emplace_back(std::move(k), value(depth + 1));
+                ws();
+                if (p < e && *p == ',') { p++; continue; }
+                if (p < e && *p == '}') { p++; break; }
+                fail("glTF JSON: expected ',' or '}'");
+            }
+        } else if (*p == '[') {
+            v.t = JV::ARR; p++; ws();
+            if (p < e && *p == ']') { p++; return v; }
+            for (;;) {
+                v.a.push_back(value(depth + 1));
+                ws();
+                if (p < e && *p == ',') { p++; continue; }
+                if (p < e && *p == ']') { p++; break; }
+                fail("glTF JSON: expected ',' or ']'");
+            }
+        } else if (*p == '"') {
+            v.t = JV::STR; v.s = string();
+        } else if (e - p >= 4 && !std::strncmp(p, "true", 4)) { v.t = JV::BOOL; v.b = true; p += 4; }
+        else if (e - p >= 5 && !std::strncmp(p, "false", 5)) { v.t = JV::BOOL; v.b = false; p += 5; }
+        else if (e - p >= 4 && !std::strncmp(p, "null", 4)) { p += 4; }
+        else {
+            std::string tok;
+            while (p < e && (std::strchr("+-.eE", *p) || (*p >= '0' && *p <= '9'))) tok.push_back(*p++);
+            if (tok.empty()) fail("glTF JSON: unexpected character");
+            char* end = nullptr;
+            v.t = JV::NUM; v.num = std::strtod(tok.c_str(), &end);
+            if (!end || *end) fail("glTF JSON: bad number");
+        }
+        return v;
+    }
+    std::string string() {
+        std::string s; p++;
+        while (p < e && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= e) break;
+                switch (*p) {
+                case 'n': s.push_back('\n'); break; case 't': s.push_back('\t'); break; case 'r': s.push_back('\r'); break;
+                case 'b': s.push_back('\b'); break; case 'f': s.push_back('\f'); break;
+                case 'u': {
+                    if (e - p < 5) fail("glTF JSON: bad \\u escape");
+                    unsigned c = (unsigned)std::strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
+                    p += 4;
+                    if (c < 0x80) s.push_back((char)c);
+                    else if (c < 0x800) { s.push_back((char)(0xC0 | (c >> 6))); s.push_back((char)(0x80 | (c & 0x3F))); }
+                    else { s.push_back((char)(0xE0 | (c >> 12))); s.push_back((char)(0x80 | ((c >> 6) & 0x3F))); s.push_back((char)(0x80 | (c & 0x3F))); }
+                    break;
+                }
+                default: s.push_back(*p);
+                }
+                p++;
+            } else s.push_back(*p++);
+        }
+        if (p >= e) fail("glTF JSON: unterminated string");
+        p++;
+        return s;
+    }
+};
+
+// ---------------------------------------------------------------- reference vector arithmetic (XYZ.cpp), float as written
+struct V3 { float X = 0, Y = 0, Z = 0; };
+struct Q4 { float X = 0, Y = 0, Z = 0, W = 0; };
+inline V3 add(V3 a, V3 b) { return {a.X + b.X, a.Y + b.Y, a.Z + b.Z}; }
+inline V3 sub(V3 a, V3 b) { return {a.X - b.X, a.Y - b.Y, a.Z - b.Z}; }
+inline V3 mul(V3 a, V3 b) { return {a.X * b.X, a.Y * b.Y, a.Z * b.Z}; }
+inline V3 scale(V3 a, float s) { return {a.X * s, a.Y * s, a.Z * s}; }
+inline V3 cross(V3 a, V3 b) { return {a.Y * b.Z - a.Z * b.Y, a.Z * b.X - a.X * b.Z, a.X * b.Y - a.Y * b.X}; }   // XYZ.cpp:292-298
+inline V3 normalize(V3 v) { const float len = std::sqrt(v.X * v.X + v.Y * v.Y + v.Z * v.Z); return {v.X / len, v.Y / len, v.Z / len}; }   // :233-240
+inline V3 apply_rotation(V3 p, Q4 r) {                                                    // XYZ.cpp:679-683
+    const V3 rv{r.X, r.Y, r.Z};
+    const V3 t = scale(cross(rv, p), 2.0f);
+    return add(add(p, scale(t, r.W)), cross(rv, t));
+}
+inline Q4 q_multiply(Q4 q2, Q4 q1) {                                                      // XYZ.cpp:626-633
+    return {q1.W * q2.X + q1.X * q2.W + q1.Y * q2.Z - q1.Z * q2.Y,
+            q1.W * q2.Y - q1.X * q2.Z + q1.Y * q2.W + q1.Z * q2.X,
+            q1.W * q2.Z + q1.X * q2.Y - q1.Y * q2.X + q1.Z * q2.W,
+            q1.W * q2.W - q1.X * q2.X - q1.Y * q2.Y - q1.Z * q2.Z};
+}
+// XYZ(std::vector<double>, swizzle) with {0,-2,1} / Quat with {0,-2,1,3} / scale with {0,2,1} (XYZ.cpp:97,613)
+inline V3 swz_pos(const JV& a) { return {(float)a.at(0).as_double(), (float)(-1 * a.at(2).as_double()), (float)(1 * a.at(1).as_double())}; }
+inline V3 swz_scale(const JV& a) { return {(float)a.at(0).as_double(), (float)a.at(2).as_double(), (float)a.at(1).as_double()}; }
+inline Q4 swz_rot(const JV& a) {
+    return {(float)a.at(0).as_double(), (float)(-1 * a.at(2).as_double()), (float)(1 * a.at(1).as_double()), (float)(1 * a.at(3).as_double())};
+}
+inline V3 swz(V3 v) { return {1 * v.X, -1 * v.Z, 1 * v.Y}; }                              // XYZ::swizzle, XYZ.cpp:115-121
+
+struct Transform { bool has_rot = false, has_move = false; Q4 rot; V3 move; };              // Transformation.h:6-27
+inline void stack(const Transform& t, V3& pos, Q4& rot) {                                   // Transformation.h:28-36
+    if (t.has_move) pos = add(pos, t.move);
+    if (t.has_rot) { rot = q_multiply(rot, t.rot); pos = apply_rotation(pos, t.rot); }
+}
+
+struct Tri { V3 p1, p2, p3; float uv[6]; V3 n1, n2, n3; int material; };
+inline Tri make_tri(V3 p1, V3 p2, V3 p3, const float* uv, int material) {                   // Primitives.h:237-252
+    Tri t; t.p1 = p1; t.p2 = p2; t.p3 = p3; std::memcpy(t.uv, uv, sizeof(t.uv)); t.material = material;
+    const V3 normal = normalize(cross(sub(p3, p1), sub(p2, p1)));
+    t.n1 = t.n2 = t.n3 = normal;
+    return t;
+}
+
+struct Object {
+    int parent = -1;
+    V3 origin, scale{1, 1, 1};
+    std::vector<Transform> transformations;
+    std::vector<int> children;
+    int mesh = -1;
+};
+
+// ---------------------------------------------------------------- inflate + PNG (images inside the .glb)
+struct BitReader {
+    const uint8_t* d; size_t n, pos = 0; uint32_t buf = 0; int cnt = 0;
+    uint32_t bits(int k) {
+        while (cnt < k) { if (pos >= n) fail("PNG: compressed data ends early"); buf |= (uint32_t)d[pos++] << cnt; cnt += 8; }
+        const uint32_t v = buf & ((k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1u));
+        buf >>= k; cnt -= k;
+        return v;
+    }
+};
+struct Huff {
+    uint16_t count[16] = {0}; uint16_t symbol[320] = {0};
+    void build(const uint8_t* len, int n) {
+        std::memset(count, 0, sizeof(count));
+        for (int i = 0; i < n; i++) count[len[i]]++;
+        count[0] = 0;
+        uint16_t offs[16]; offs[1] = 0;
+        for (int i = 1; i < 15; i++) offs[i + 1] = offs[i] + count[i];
+        for (int i = 0; i < n; i++) if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+    }
+    int decode(BitReader& br) const {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; len++) {
+            code |= (int)br.bits(1);
+            const int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        fail("PNG: bad Huffman code");
+    }
+};
+std::vector<uint8_t> inflate_zlib(const uint8_t* d, size_t n) {
+    if (n < 6) fail("PNG: zlib stream too short");
+    BitReader br{d + 2, n - 2};
+    std::vector<uint8_t> out;
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (bool last = false; !last;) {
+        last = br.bits(1) != 0;
+        const uint32_t type = br.bits(2);
+        if (type == 0) {
+            br.buf = 0; br.cnt = 0;
+            if (br.pos + 4 > br.n) fail("PNG: stored block header cut off");
+            const uint32_t len = br.d[br.pos] | (br.d[br.pos + 1] << 8);
+            br.pos += 4;
+            if (br.pos + len > br.n) fail("PNG: stored block cut off");
+            out.insert(out.end(), br.d + br.pos, br.d + br.pos + len);
+            br.pos += len;
+            continue;
+        }
+        if (type == 3) fail("PNG: bad deflate block type");
+        Huff lit, dist;
+        uint8_t lens[320];
+        if (type == 1) {
+            for (int i = 0; i < 144; i++) lens[i] = 8;
+            for (int i = 144; i < 256; i++) lens[i] = 9;
+            for (int i = 256; i < 280; i++) lens[i] = 7;
+            for (int i = 280; i < 288; i++) lens[i] = 8;
+            lit.build(lens, 288);
+            for (int i = 0; i < 30; i++) lens[i] = 5;
+            dist.build(lens, 30);
+        } else {
+            const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t cl[19] = {0};
+            for (int i = 0; i < ncode; i++) cl[order[i]] = (uint8_t)br.bits(3);
+            Huff h; h.build(cl, 19);
+            int i = 0;
+            while (i < nlen + ndist) {
+                const int sym = h.decode(br);
+                if (sym < 16) lens[i++] = (uint8_t)sym;
+                else {
+                    int rep; uint8_t v = 0;
+                    if (sym == 16) { if (i == 0) fail("PNG: bad code lengths"); v = lens[i - 1]; rep = 3 + (int)br.bits(2); }
+                    else if (sym == 17) rep = 3 + (int)br.bits(3);
+                    else rep = 11 + (int)br.bits(7);
+                    if (i + rep > nlen + ndist) fail("PNG: bad code lengths");
+                    while (rep--) lens[i++] = v;
+                }
+            }
+            lit.build(lens, nlen);
+            dist.build(lens + nlen, ndist);
+        }
+        for (;;) {
+            const int sym = lit.decode(br);
+            if (sym < 256) out.push_back((uint8_t)sym);
+            else if (sym == 256) break;
+            else {
+                if (sym > 285) fail("PNG: bad length symbol");
+                const int len = lbase[sym - 257] + (int)br.bits(lext[sym - 257]);
+                const int ds = dist.decode(br);
+                if (ds > 29) fail("PNG: bad distance symbol");
+                const size_t dd = dbase[ds] + br.bits(dext[ds]);
+                if (dd > out.size()) fail("PNG: distance beyond the start");
+                for (int k = 0; k < len; k++) out.push_back(out[out.size() - dd]);
+            }
+        }
+    }
+    return out;
+}
+
+struct Image { int w = 0, h = 0, comp = 0; std::vector<uint8_t> px; };   // comp 3 or 4, rows top to bottom (stb_image layout)
+Image decode_png(const uint8_t* d, size_t n) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (n < 8 || std::memcmp(d, sig, 8)) fail("image is not a PNG (only 8-bit non-interlaced PNG images are decoded; the reference uses stb_image)");
+    Image im; int ctype = -1;
+    std::vector<uint8_t> z, plte;
+    for (size_t at = 8; at + 12 <= n;) {
+        const uint32_t len = (uint32_t)d[at] << 24 | d[at + 1] << 16 | d[at + 2] << 8 | d[at + 3];
+        const char* ty = (const char*)d + at + 4;
+        const uint8_t* body = d + at + 8;
+        if (at + 12 + (size_t)len > n) fail("PNG: chunk cut off");
+        if (!std::strncmp(ty, "IHDR", 4)) {
+            if (len < 13) fail("PNG: bad IHDR");
+            im.w = (int)((uint32_t)body[0] << 24 | body[1] << 16 | body[2] << 8 | body[3]);
+            im.h = (int)((uint32_t)body[4] << 24 | body[5] << 16 | body[6] << 8 | body[7]);
+            ctype = body[9];
+            if (body[8] != 8 || body[12] != 0 || !(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 4 || ctype == 6))
+                fail("PNG: only 8-bit non-interlaced images are decoded");
+        } else if (!std::strncmp(ty, "PLTE", 4)) plte.assign(body, body + len);
+        else if (!std::strncmp(ty, "IDAT", 4)) z.insert(z.end(), body, body + len);
+        else if (!std::strncmp(ty, "IEND", 4)) break;
+        at += 12 + (size_t)len;
+    }
+    if (im.w <= 0 || im.h <= 0 || ctype < 0) fail("PNG: no IHDR");
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
+    const size_t stride = (size_t)im.w * ch;
+    std::vector<uint8_t> raw = inflate_zlib(z.data(), z.size());
+    if (raw.size() < (stride + 1) * (size_t)im.h) fail("PNG: pixel data too short");
+    std::vector<uint8_t> img(stride * im.h);
+    for (int y = 0; y < im.h; y++) {
+        const uint8_t* in = raw.data() + (stride + 1) * y;
+        uint8_t* cur = img.data() + stride * y;
+        const uint8_t* up = y ? cur - stride : nullptr;
+        const int f = in[0];
+        for (size_t x = 0; x < stride; x++) {
+            const int a = x >= (size_t)ch ? cur[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+            int v = in[1 + x];
+            switch (f) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                      v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+            default: fail("PNG: bad filter");
+            }
+            cur[x] = (uint8_t)v;
+        }
+    }
+    // to RGB / RGBA like stb_image with req_comp 0 would give for colour images (tinygltf asks for 4 components: RGBA)
+    im.comp = 4;
+    im.px.resize((size_t)im.w * im.h * 4);
+    for (size_t i = 0; i < (size_t)im.w * im.h; i++) {
+        uint8_t r, g, b, a = 255;
+        const uint8_t* s = img.data() + i * ch;
+        if (ctype == 0) { r = g = b = s[0]; }
+        else if (ctype == 4) { r = g = b = s[0]; a = s[1]; }
+        else if (ctype == 3) { if ((size_t)s[0] * 3 + 2 >= plte.size()) fail("PNG: palette index out of range"); r = plte[s[0] * 3]; g = plte[s[0] * 3 + 1]; b = plte[s[0] * 3 + 2]; }
+        else { r = s[0]; g = s[1]; b = s[2]; if (ctype == 6) a = s[3]; }
+        im.px[4 * i] = r; im.px[4 * i + 1] = g; im.px[4 * i + 2] = b; im.px[4 * i + 3] = a;
+    }
+    return im;
+}
+
+// ---------------------------------------------------------------- textures as the reference stores them (Texture.h, USE_CHAR 1)
+struct Tex { int w = 0, h = 0; std::vector<uint8_t> rgb; bool normal_transform = false; float sx = 1, sy = 1; };
+inline uint8_t to_uchar(float v) { return (uint8_t)(int)v; }                      // float -> unsigned char, truncation
+enum Conv { CONV_XYZ, CONV_SRGB };
+
+// ImageHandler::apply_gamma(in, 1 / 2.2) (ImageProcessing.h:128-133 via FileLoading.h:361-363)
+inline V3 gamma_srgb(V3 in) {
+    const float gamma = (float)(1 / 2.2);
+    const float lums = in.X * 0.2126f + in.Y * 0.7152f + in.Z * 0.0722f;
+    if (lums == 0) return {0, 0, 0};
+    const float post = (float)std::pow((double)lums, 1.0 / (double)gamma);
+    return {in.X * post / lums, in.Y * post / lums, in.Z * post / lums};
+}
+
+// Texture::load (Texture.h:36-67,94-102): `position += components` BEFORE the read
+Tex load_texture(const Image& im, Conv conv, bool with_scale, float scale_v) {
+    Tex t; t.w = im.w; t.h = im.h; t.rgb.assign((size_t)im.w * im.h * 3, 0);
+    t.normal_transform = with_scale;
+    std::vector<uint8_t> img(im.px);
+    img.resize(img.size() + 8, 0);                     // the read one texel past the end
+    size_t position = 0;
+    for (int y = 0; y < im.h; y++)
+        for (int x = 0; x < im.w; x++) {
+            position += (size_t)im.comp;
+            const float r = ((float)img[position + 0]) / 255.0f, g = ((float)img[position + 1]) / 255.0f, b = ((float)img[position + 2]) / 255.0f;
+            V3 v{r, g, b};
+            if (conv == CONV_SRGB) v = gamma_srgb(v);
+            uint8_t* o = &t.rgb[((size_t)y * im.w + x) * 3];
+            if (with_scale) {                          // load_with_scale + commit_char with use_normal_transform
+                const V3 in2 = sub(scale(v, 2.0f), V3{1, 1, 1});
+                const V3 nv = normalize(mul(in2, V3{scale_v, scale_v, 1.0f}));
+                o[0] = to_uchar(nv.X * 127 + 128); o[1] = to_uchar(nv.Y * 127 + 128); o[2] = to_uchar(nv.Z * 127 + 128);
+            } else {
+                o[0] = to_uchar(v.X * 255); o[1] = to_uchar(v.Y * 255); o[2] = to_uchar(v.Z * 255);
+            }
+        }
+    return t;
+}
+// Texture::export_channel (Texture.h:214-226): value of one channel, re-quantised into byte 0 of a 3-byte texel
+Tex export_channel(const Tex& src, int channel) {
+    Tex t; t.w = src.w; t.h = src.h; t.sx = src.sx; t.sy = src.sy; t.rgb.assign(src.rgb.size(), 0);
+    for (size_t i = 0; i < (size_t)src.w * src.h; i++) {
+        const float v = src.rgb[3 * i + channel] / 255.0f;                        // fetch_char_XYZ (:147-155)
+        t.rgb[3 * i] = to_uchar(v * 255);                                         // commit_char(float) (:133-136)
+    }
+    return t;
+}
+
+}  // namespace
+
+struct srx_gltf {
+    std::vector<srx_tri> tris;
+    std::vector<srx_material> materials;
+    std::vector<Tex> tex;
+    std::vector<srx_texture> textures;
+    std::vector<srx_sun> suns;
+    srx_camera camera;
+};
+
+namespace {
+
+struct Loader {
+    JV root;
+    std::vector<uint8_t> bin;
+    srx_gltf* out;
+
+    // ---- accessors (FileLoading.h:231-347)
+    struct View { const uint8_t* p; size_t stride; size_t count; int comp_type; int ncomp; };
+    View view(int accessor, int want_comp_type_a, int want_comp_type_b, int want_ncomp) {
+        const JV& acc = root.get("accessors") ? root.get("accessors")->at((size_t)accessor) : JV();
+        if (acc.t != JV::OBJ) fail("glTF: accessor index out of range");
+        const int ct = acc.integer("componentType", 0);
+        if (ct != want_comp_type_a && ct != want_comp_type_b) fail("glTF: accessor has an unsupported component type (floats for vertex data, u16/u32 for indices)");
+        const std::string ty = acc.str("type");
+        const int nc = ty == "SCALAR" ? 1 : ty == "VEC2" ? 2 : ty == "VEC3" ? 3 : ty == "VEC4" ? 4 : 0;
+        if (nc != want_ncomp) fail("glTF: accessor has the wrong element type (" + ty + ")");
+        const JV& bv = root.get("bufferViews") ? root.get("bufferViews")->at((size_t)acc.integer("bufferView", -1)) : JV();
+        if (bv.t != JV::OBJ) fail("glTF: accessor without a bufferView");
+        if (bv.integer("buffer", 0) != 0) fail("glTF: only the binary chunk of the .glb is supported as a buffer");
+        const size_t csz = (ct == 5123) ? 2 : 4;
+        const size_t off = (size_t)bv.number("byteOffset", 0) + (size_t)acc.number("byteOffset", 0);
+        const size_t stride = bv.has("byteStride") ? (size_t)bv.number("byteStride", 0) : csz * nc;
+        const size_t count = (size_t)acc.number("count", 0);
+        if (count && off + stride * (count - 1) + csz * nc > bin.size()) fail("glTF: accessor reaches beyond the binary chunk");
+        return {bin.data() + off, stride, count, ct, nc};
+    }
+    std::vector<V3> vec3(int accessor) {
+        View v = view(accessor, 5126, 5126, 3);
+        std::vector<V3> r(v.count);
+        for (size_t i = 0; i < v.count; i++) std::memcpy(&r[i], v.p + i * v.stride, 12);
+        return r;
+    }
+    std::vector<float> vec2(int accessor) {
+        View v = view(accessor, 5126, 5126, 2);
+        std::vector<float> r(v.count * 2);
+        for (size_t i = 0; i < v.count; i++) std::memcpy(&r[2 * i], v.p + i * v.stride, 8);
+        return r;
+    }
+    std::vector<uint32_t> indices(int accessor) {
+        View v = view(accessor, 5125, 5123, 1);
+        std::vector<uint32_t> r(v.count);
+        for (size_t i = 0; i < v.count; i++) {
+            if (v.comp_type == 5125) std::memcpy(&r[i], v.p + i * v.stride, 4);
+            else { uint16_t s; std::memcpy(&s, v.p + i * v.stride, 2); r[i] = s; }
+        }
+        return r;
+    }
+
+    // ---- textures (TextureLoader, FileLoading.h:17-165; fetch_transform :410-437)
+    std::map<std::pair<int, std::pair<int, float>>, int> tex_cache;     // (gltf texture, converter, scale) -> base Tex index
+    std::vector<Tex> base;
+    int base_texture(int t_index, Conv conv, bool with_scale, float scale_v) {
+        auto key = std::make_pair(t_index, std::make_pair((int)conv + (with_scale ? 2 : 0), with_scale ? scale_v : -9999.0f));
+        auto it = tex_cache.find(key);
+        if (it != tex_cache.end()) return it->second;
+        const JV& td = root.get("textures") ? root.get("textures")->at((size_t)t_index) : JV();
+        if (td.t != JV::OBJ) fail("glTF: texture index out of range");
+        const JV& im = root.get("images") ? root.get("images")->at((size_t)td.integer("source", -1)) : JV();
+        if (im.t != JV::OBJ) fail("glTF: texture without an image");
+        if (!im.has("bufferView")) fail("glTF: image \"" + im.str("name") + "\" is not embedded in the .glb (uri images are not read)");
+        const JV& bv = root.get("bufferViews") ? root.get("bufferViews")->at((size_t)im.integer("bufferView", -1)) : JV();
+        if (bv.t != JV::OBJ) fail("glTF: image bufferView out of range");
+        const size_t off = (size_t)bv.number("byteOffset", 0), len = (size_t)bv.number("byteLength", 0);
+        if (off + len > bin.size()) fail("glTF: image reaches beyond the binary chunk");
+        const Image img = decode_png(bin.data() + off, len);
+        base.push_back(load_texture(img, conv, with_scale, scale_v));
+        return tex_cache[key] = (int)base.size() - 1;
+    }
+    static void transform_of(const JV* info, float& sx, float& sy) {
+        sx = 1; sy = 1;
+        if (!info) return;
+        const JV* ext = info->get("extensions");
+        const JV* tt = ext ? ext->get("KHR_texture_transform") : nullptr;
+        if (!tt) return;
+        const JV* sc = tt->get("scale");
+        static const JV nul;
+        sx = (float)(sc ? sc->at(0) : nul).as_double(); sy = (float)(sc ? sc->at(1) : nul).as_double();
+    }
+    int add_texture(Tex t) { out->tex.push_back(std::move(t)); return (int)out->tex.size() - 1; }
+
+    std::vector<int> uv_map_index;     // Material::UV_map_index per material
+
+    void materials() {
+        const JV* ms = root.get("materials");
+        for (size_t mi = 0; ms && mi < ms->size(); mi++) {
+            const JV& md = ms->at(mi);
+            static const JV empty;
+            const JV& pbr = md.get("pbrMetallicRoughness") ? *md.get("pbrMetallicRoughness") : empty;
+            srx_material m;
+            std::memset(&m, 0, sizeof(m));
+            m.color_tex = m.roughness_tex = m.metallic_tex = m.specular_tex = m.emissive_tex = m.normal_tex = m.transmission_tex = m.ior_tex = -1;
+            const JV* bc = pbr.get("baseColorFactor");
+            for (int k = 0; k < 3; k++) m.color[k] = bc ? (float)bc->at(k).as_double() : 1.0f;                  // :470
+            const double metallic_factor = pbr.number("metallicFactor", 1.0), roughness_factor = pbr.number("roughnessFactor", 1.0);
+            m.metallic = (float)metallic_factor; m.roughness = (float)roughness_factor;                          // :471-472
+            const JV* em = md.get("emissiveFactor");
+            for (int k = 0; k < 3; k++) m.emissive[k] = (em ? (float)em->at(k).as_double() : 0.0f) * 25;         // :473
+            int uv_index = 0;
+            const JV* bct = pbr.get("baseColorTexture");
+            if (bct && bct->integer("index", -1) != -1) {                                                        // :477-487
+                uv_index = bct->integer("texCoord", 0);
+                Tex t = base[base_texture(bct->integer("index", -1), CONV_SRGB, false, 0)];
+                transform_of(bct, t.sx, t.sy);
+                m.color_tex = add_texture(std::move(t));
+            }
+            const JV* mrt = pbr.get("metallicRoughnessTexture");
+            if (mrt && mrt->integer("index", -1) != -1) {                                                        // :488-518
+                uv_index = bct ? bct->integer("texCoord", 0) : 0;
+                Tex t = base[base_texture(mrt->integer("index", -1), CONV_XYZ, false, 0)];
+                transform_of(mrt, t.sx, t.sy);
+                Tex metallic = export_channel(t, 2), roughness = export_channel(t, 1);
+                if (metallic_factor != 0) {
+                    if (metallic_factor != 1)
+                        for (size_t i = 0; i < (size_t)metallic.w * metallic.h; i++) metallic.rgb[i] = (uint8_t)(int)(metallic.rgb[i] * metallic_factor);
+                    m.metallic_tex = add_texture(std::move(metallic));
+                }
+                if (roughness_factor != 0) m.roughness_tex = add_texture(std::move(roughness));
+            }
+            const JV* nt = md.get("normalTexture");
+            if (nt && nt->integer("index", -1) != -1) {                                                          // :519-534
+                uv_index = nt->integer("texCoord", 0);
+                const float s = (float)nt->number("scale", 1.0);
+                Tex t = base[base_texture(nt->integer("index", -1), CONV_XYZ, true, s)];
+                transform_of(nt, t.sx, t.sy);
+                m.normal_tex = add_texture(std::move(t));
+                m.use_normals = 1;
+            }
+            const JV* ext = md.get("extensions");
+            if (ext && ext->has("KHR_materials_specular")) {                                                     // :535-552
+                const JV* f = ext->get("KHR_materials_specular")->get("specularColorFactor");
+                m.specular = (f && f->t != JV::NUL) ? (float)f->at(0).as_double() : 0.0f;
+            } else m.specular = 1;
+            if (ext && ext->has("KHR_materials_ior")) {                                                          // :553-563
+                const JV* f = ext->get("KHR_materials_ior")->get("ior");
+                m.ior = (float)(f ? f->as_double() : 0.0);
+            } else m.ior = 1.5;
+            if (ext && ext->has("KHR_materials_transmission")) {                                                 // :564-574
+                const JV* f = ext->get("KHR_materials_transmission")->get("transmissionFactor");
+                m.transmission = (float)(f ? f->as_double() : 0.0);
+            } else m.transmission = 0;
+            out->materials.push_back(m);
+            uv_map_index.push_back(uv_index);
+        }
+        srx_material d;                                                                                          // :579-587
+        std::memset(&d, 0, sizeof(d));
+        d.color_tex = d.roughness_tex = d.metallic_tex = d.specular_tex = d.emissive_tex = d.normal_tex = d.transmission_tex = d.ior_tex = -1;
+        d.roughness = 0.5f; d.ior = 1.5f; d.color[0] = d.color[1] = d.color[2] = 1; d.metallic = 0;
+        out->materials.push_back(d);
+        uv_map_index.push_back(0);
+    }
+
+    std::vector<std::vector<Tri>> meshes;
+    void load_meshes() {                                                                                         // :588-674
+        const int default_index = (int)out->materials.size() - 1;
+        const JV* ms = root.get("meshes");
+        for (size_t mi = 0; ms && mi < ms->size(); mi++) {
+            std::vector<Tri> tris;
+            const JV* prims = ms->at(mi).get("primitives");
+            for (size_t pi = 0; prims && pi < prims->size(); pi++) {
+                const JV& pr = prims->at(pi);
+                static const JV empty;
+                const JV& attr = pr.get("attributes") ? *pr.get("attributes") : empty;
+                int mat = pr.integer("material", -1);
+                if (mat <= -1) mat = default_index;
+                if (mat >= (int)out->materials.size() - 1 && mat != default_index) fail("glTF: primitive material out of range");
+                if (!attr.has("POSITION")) fail("glTF: primitive without POSITION");
+                if (pr.has("mode") && pr.integer("mode", 4) != 4) fail("glTF: only triangle lists (mode 4) are read");
+                const int pos_acc = attr.integer("POSITION", 0);
+                const std::string tc = "TEXCOORD_" + std::to_string(uv_map_index[(size_t)mat]);
+                const int tex_acc = attr.integer(tc.c_str(), 0), nrm_acc = attr.integer("NORMAL", 0);
+                const std::vector<V3> P = vec3(pos_acc);
+                const bool uv_mapped = tex_acc != 0, smooth = nrm_acc != 0;                                       // :614,620
+                std::vector<float> UV; std::vector<V3> N;
+                if (uv_mapped) UV = vec2(tex_acc);
+                if (smooth) N = vec3(nrm_acc);
+                if (!pr.has("indices")) fail("glTF: primitive without indices");
+                const std::vector<uint32_t> idx = indices(pr.integer("indices", -1));
+                if (idx.size() % 3) fail("glTF: index count is not a multiple of 3");
+                for (size_t i = 0; i < idx.size() / 3; i++) {
+                    const uint32_t l[3] = {idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]};
+                    float uv[6] = {0, 0, 0, 0, 0, 0};
+                    for (int k = 0; k < 3; k++) {
+                        if (l[k] >= P.size() || (uv_mapped && l[k] * 2 + 1 >= UV.size()) || (smooth && l[k] >= N.size())) fail("glTF: vertex index out of range");
+                        if (uv_mapped) { uv[2 * k] = 0.0f - (-1.0f * UV[2 * l[k]]); uv[2 * k + 1] = 1.0f - (1.0f * UV[2 * l[k] + 1]); }   // :658-660
+                    }
+                    Tri t = make_tri(swz(P[l[0]]), swz(P[l[1]]), swz(P[l[2]]), uv, mat);
+                    if (smooth) { t.n1 = swz(N[l[0]]); t.n2 = swz(N[l[1]]); t.n3 = swz(N[l[2]]); }
+                    tris.push_back(t);
+                }
+            }
+            meshes.push_back(std::move(tris));
+        }
+    }
+
+    struct Cam { V3 position; Q4 rotation{0, 0, 0, 1}; float aspect = 1, distance = 1; };
+    std::vector<Cam> cameras;
+    std::vector<Object> objects;
+    std::vector<srx_sun> lights;
+    std::map<int, std::pair<int, int>> node_lookup;
+
+    void load_nodes() {
+        const JV* cs = root.get("cameras");
+        for (size_t i = 0; cs && i < cs->size(); i++) {                                                          // :677-685
+            if (cs->at(i).str("type") != "perspective") fail("glTF: only perspective cameras are read");
+            static const JV empty;
+            const JV& p = cs->at(i).get("perspective") ? *cs->at(i).get("perspective") : empty;
+            Cam c;
+            c.aspect = (float)p.number("aspectRatio", 0.0);
+            c.distance = (float)(0.5 / std::tan(0.5 * p.number("yfov", 0.0)));
+            cameras.push_back(c);
+        }
+        const JV* ext = root.get("extensions");
+        const JV* lp = ext ? ext->get("KHR_lights_punctual") : nullptr;
+        const JV* light_defs = lp ? lp->get("lights") : nullptr;
+        const JV* ns = root.get("nodes");
+        for (size_t ni = 0; ns && ni < ns->size(); ni++) {                                                       // :686-742
+            const JV& nd = ns->at(ni);
+            const JV* sc = nd.get("scale"); const JV* tr = nd.get("translation"); const JV* ro = nd.get("rotation");
+            const bool has_s = sc && sc->size() > 0, has_t = tr && tr->size() > 0, has_r = ro && ro->size() > 0;
+            const int cam = nd.integer("camera", -1), mesh = nd.integer("mesh", -1);
+            const JV* next = nd.get("extensions");
+            const JV* nl = next ? next->get("KHR_lights_punctual") : nullptr;
+            const int light = nl ? nl->integer("light", -1) : -1;
+            if (cam > -1) {
+                if ((size_t)cam >= cameras.size()) fail("glTF: node camera out of range");
+                if (has_t) cameras[(size_t)cam].position = add(cameras[(size_t)cam].position, swz_pos(*tr));
+                cameras[(size_t)cam].rotation = has_r ? swz_rot(*ro) : Q4{0, 0, 0, 0};                           // Quat() : W(0)
+                node_lookup[(int)ni] = {0, cam};
+                continue;
+            }
+            if (mesh > -1) {
+                if ((size_t)mesh >= meshes.size()) fail("glTF: node mesh out of range");
+                Object o;
+                if (has_s) o.scale = swz_scale(*sc);
+                Transform r; r.has_rot = true; r.rot = has_r ? swz_rot(*ro) : Q4{0, 0, 0, 1};
+                Transform m; m.has_move = true; m.move = has_t ? swz_pos(*tr) : V3{0, 0, 0};
+                o.transformations.push_back(r); o.transformations.push_back(m);                                  // :711-712
+                o.mesh = mesh;
+                objects.push_back(o);
+                node_lookup[(int)ni] = {1, (int)objects.size() - 1};
+                continue;
+            }
+            if (light > -1) {
+                const JV& ld = light_defs ? light_defs->at((size_t)light) : JV();
+                if (ld.t != JV::OBJ) fail("glTF: node light out of range");
+                const Q4 rot = has_r ? swz_rot(*ro) : Q4{0, 0, 0, 1};
+                if (ld.str("type") == "directional") {                                                           // :724-732
+                    const V3 dir = apply_rotation(V3{0, -1, 0}, rot);
+                    const JV* col = ld.get("color");
+                    const float intensity = (float)ld.number("intensity", 1.0);
+                    srx_sun s;
+                    const float d3[3] = {dir.X, dir.Y, dir.Z};
+                    for (int k = 0; k < 3; k++) { s.direction[k] = d3[k]; s.emission[k] = (col ? (float)col->at(k).as_double() : 1.0f) * intensity / 50000; }
+                    lights.push_back(s);
+                    node_lookup[(int)ni] = {2, (int)lights.size() - 1};
+                } else fail("glTF: light type \"" + ld.str("type") + "\" is not supported (the reference only builds SunLight)");
+                continue;
+            }
+        }
+        for (auto& kv : node_lookup) {                                                                           // :743-755 (mesh nodes only)
+            if (kv.second.first != 1) continue;
+            const JV* ch = ns->at((size_t)kv.first).get("children");
+            for (size_t c = 0; ch && c < ch->size(); c++) {
+                auto it = node_lookup.find((int)ch->at(c).as_double());
+                if (it == node_lookup.end() || it->second.first != 1) continue;
+                objects[(size_t)kv.second.second].children.push_back(it->second.second);
+                objects[(size_t)it->second.second].parent = kv.second.second;
+            }
+        }
+    }
+
+    V3 compile_scale(int oi, V3 s) {                                                                             // Primitives.h:462-471
+        s = mul(s, objects[(size_t)oi].scale);
+        if (objects[(size_t)oi].parent >= 0) s = mul(s, compile_scale(objects[(size_t)oi].parent, s));
+        return s;
+    }
+    void compile_transforms(int oi, std::vector<Transform>& in) {                                                // :472-481
+        for (auto& t : objects[(size_t)oi].transformations) in.push_back(t);
+        if (objects[(size_t)oi].parent >= 0) compile_transforms(objects[(size_t)oi].parent, in);
+    }
+    void fetch_data(int oi, int depth) {                                                                         // :423-434, Packers::transformT :347-373
+        if (depth > 256) fail("glTF: node hierarchy too deep (a cycle?)");
+        const Object& o = objects[(size_t)oi];
+        const V3 scale_final = compile_scale(oi, V3{1, 1, 1});
+        std::vector<Transform> all;
+        compile_transforms(oi, all);
+        V3 position{0, 0, 0}; Q4 rotation{0, 0, 0, 1};
+        for (auto& t : all) stack(t, position, rotation);                                                        // Transformation::collpase
+        for (const Tri& t : meshes[(size_t)o.mesh]) {
+            V3 np[3] = {sub(t.p1, o.origin), sub(t.p2, o.origin), sub(t.p3, o.origin)};
+            for (auto& p : np) { p = mul(p, scale_final); p = apply_rotation(p, rotation); p = add(p, position); p = add(p, o.origin); }
+            const V3 nn[3] = {apply_rotation(t.n1, rotation), apply_rotation(t.n2, rotation), apply_rotation(t.n3, rotation)};
+            srx_tri s;
+            for (int k = 0; k < 3; k++) {
+                s.p[3 * k] = np[k].X; s.p[3 * k + 1] = np[k].Y; s.p[3 * k + 2] = np[k].Z;
+                s.n[3 * k] = nn[k].X; s.n[3 * k + 1] = nn[k].Y; s.n[3 * k + 2] = nn[k].Z;
+            }
+            std::memcpy(s.uv, t.uv, sizeof(s.uv));
+            s.material = t.material; s.flags = 1u;       // the rotated normals of the ORIGINAL triangle are kept (transformT)
+            out->tris.push_back(s);
+        }
+        for (int c : o.children) fetch_data(c, depth + 1);
+    }
+
+    void run() {
+        materials();
+        load_meshes();
+        load_nodes();
+        // scene registration in node order (:759-777; an index that is no camera / mesh / light node registers camera 0)
+        int camera = -1, last = -1;
+        for (auto& kv : node_lookup) last = std::max(last, kv.first);
+        std::vector<int> roots;
+        for (int i = 0; i <= last; i++) {
+            auto it = node_lookup.find(i);
+            const int type = it == node_lookup.end() ? 0 : it->second.first, index = it == node_lookup.end() ? 0 : it->second.second;
+            if (type == 0 && camera < 0 && !cameras.empty()) camera = index;
+            if (type == 1 && objects[(size_t)index].parent < 0) roots.push_back(index);
+            if (type == 2) out->suns.push_back(lights[(size_t)index]);
+        }
+        if (camera < 0) fail("glTF: the scene has no camera node (the reference takes scene->cameras[0])");
+        for (int r : roots) fetch_data(r, 0);                                                                    // Scene::package, Scene.h:104-106
+        const Cam& c = cameras[(size_t)camera];
+        std::memset(&out->camera, 0, sizeof(out->camera));
+        out->camera.position[0] = c.position.X; out->camera.position[1] = c.position.Y; out->camera.position[2] = c.position.Z;
+        out->camera.rotation[0] = c.rotation.X; out->camera.rotation[1] = c.rotation.Y; out->camera.rotation[2] = c.rotation.Z; out->camera.rotation[3] = c.rotation.W;
+        out->camera.focal_position[1] = c.distance;                                                              // Camera(XYZ(), lens, XYZ(0, distance, 0)), :683
+        out->camera.lens_width = c.aspect; out->camera.lens_height = 1;                                          // RectLens(aspect_ratio, 1), :681
+        for (auto& t : out->tex) {
+            srx_texture st;
+            st.rgb8 = t.rgb.data(); st.width = t.w; st.height = t.h; st.scale_x = t.sx; st.scale_y = t.sy; st.normal_transform = t.normal_transform ? 1 : 0;
+            out->textures.push_back(st);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int srx_gltf_load(const char* path, srx_gltf** out) {
+    if (!path || !out) { srx_set_error("srx_gltf_load: null argument"); return 1; }
+    *out = nullptr;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { srx_set_error(std::string("srx_gltf_load: cannot open ") + path); return 1; }
+    std::vector<uint8_t> file;
+    uint8_t buf[1 << 16];
+    for (size_t n; (n = std::fread(buf, 1, sizeof(buf), f)) > 0;) file.insert(file.end(), buf, buf + n);
+    std::fclose(f);
+    std::unique_ptr<srx_gltf> g(new srx_gltf());
+    try {
+        auto u32 = [&](size_t at) { uint32_t v; std::memcpy(&v, file.data() + at, 4); return v; };
+        if (file.size() < 20 || u32(0) != 0x46546C67u) fail("not a binary glTF (.glb) file (the reference loads .glb only, FileLoading.h:208)");
+        if (u32(4) != 2) fail("glTF container version is not 2");
+        Loader L;
+        L.out = g.get();
+        bool have_json = false;
+        for (size_t at = 12; at + 8 <= file.size();) {
+            const uint32_t len = u32(at), type = u32(at + 4);
+            if (at + 8 + (size_t)len > file.size()) fail("glTF chunk reaches beyond the file");
+            if (type == 0x4E4F534Au) { JParser P{(const char*)file.data() + at + 8, (const char*)file.data() + at + 8 + len}; L.root = P.parse(); have_json = true; }
+            else if (type == 0x004E4942u && L.bin.empty()) L.bin.assign(file.begin() + at + 8, file.begin() + at + 8 + len);
+            at += 8 + (size_t)len;
+        }
+        if (!have_json || L.root.t != JV::OBJ) fail("glTF file has no JSON chunk");
+        L.run();
+    } catch (const Fail& e) {
+        srx_set_error(std::string("srx_gltf_load: ") + path + ": " + e.msg);
+        return 1;
+    } catch (const std::exception& e) {
+        srx_set_error(std::string("srx_gltf_load: ") + path + ": " + e.what());
+        return 1;
+    }
+    *out = g.release();
+    return 0;
+}
+
+extern "C" void srx_gltf_destroy(srx_gltf* g) { delete g; }
+
+extern "C" int srx_gltf_get(const srx_gltf* g, const srx_tri** tris, uint32_t* n_tris, const srx_material** materials, uint32_t* n_materials,
+                            const srx_texture** textures, uint32_t* n_textures, const srx_sun** suns, uint32_t* n_suns, srx_camera* camera) {
+    if (!g) { srx_set_error("srx_gltf_get: null handle"); return 1; }
+    if (tris) *tris = g->tris.data();
+    if (n_tris) *n_tris = (uint32_t)g->tris.size();
+    if (materials) *materials = g->materials.data();
+    if (n_materials) *n_materials = (uint32_t)g->materials.size();
+    if (textures) *textures = g->textures.data();
+    if (n_textures) *n_textures = (uint32_t)g->textures.size();
+    if (suns) *suns = g->suns.data();
+    if (n_suns) *n_suns = (uint32_t)g->suns.size();
+    if (camera) *camera = g->camera;
+    return 0;
+}

@@ -1,8 +1,7 @@
 """Procedural scene descriptions for the trace-and-shade path.
 
-The reference ships no scene assets (its `Assets/` holds UI icons only) and its
-glTF loader (`FileLoading.h:438-782`) is out of scope, so every workload is
-generated here as plain data: world-space authoring triangles (what
+The reference ships no scene assets (its `Assets/` holds UI icons only), so every
+benchmark workload is generated here as plain data (`.glb` files go through `gltf.py`): world-space authoring triangles (what
 `Object::fetchData`, `Primitives.h:423-434`, hands to `Scene::package`),
 a material table (`Materials.h:317-358`), RGB8 textures (`Texture.h`), sun
 lights (`FileLoading.h:724-732`) and a camera (`Camera.h`, `FileLoading.h:678-684`).
