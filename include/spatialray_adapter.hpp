@@ -118,6 +118,14 @@ public:
               "srx_trace_pass_interleaved");
         return c;
     }
+    // several consecutive passes in one call: their rays share the kernel launches (a share of a frame keeps the GPU full)
+    srx_counters trace_passes_interleaved(const srx_camera& cam, int x0, int y0, int w, int h, int group_rows, int part, int nparts,
+                                          uint32_t pass, int n_passes, uint64_t seed, float* d_accum4, float* d_aux4) {
+        srx_counters c{};
+        check(srx_trace_passes_interleaved(renderer(), &cam, x0, y0, w, h, group_rows, part, nparts, pass, n_passes, seed, d_accum4,
+                                           d_aux4, &c), "srx_trace_passes_interleaved");
+        return c;
+    }
     srx_scene* scene() const { return scene_; }
 
 private:
@@ -136,5 +144,34 @@ private:
     srx_renderer* renderer_ = nullptr;
     uint64_t capacity_;
 };
+
+// FileManager (FileLoading.h): scene in, raw frame out
+namespace FileManager {
+struct GltfScene {                                               // what parseGLTFData leaves in Scene, flattened (FileLoading.h:438-782)
+    std::vector<srx_tri> tris; std::vector<srx_material> materials; std::vector<srx_texture> textures; std::vector<srx_sun> suns;
+    srx_camera camera{};
+    srx_gltf* handle = nullptr;                                  // owns the texture bytes the srx_texture records point to
+    GltfScene() = default;
+    GltfScene(const GltfScene&) = delete;
+    GltfScene& operator=(const GltfScene&) = delete;
+    ~GltfScene() { srx_gltf_destroy(handle); }
+};
+inline void loadGLTFFile(const std::string& fName, GltfScene& out) {   // FileLoading.h:200-224
+    check(srx_gltf_load(fName.c_str(), &out.handle), "srx_gltf_load");
+    const srx_tri* t; const srx_material* m; const srx_texture* x; const srx_sun* s; uint32_t nt, nm, nx, ns;
+    check(srx_gltf_get(out.handle, &t, &nt, &m, &nm, &x, &nx, &s, &ns, &out.camera), "srx_gltf_get");
+    out.tris.assign(t, t + nt); out.materials.assign(m, m + nm); out.textures.assign(x, x + nx); out.suns.assign(s, s + ns);
+}
+inline void writeRawFile(const float* d_accum4, int res_x, int res_y, const std::string& fName) {   // FileLoading.h:166-182
+    check(srx_write_raw(fName.c_str(), d_accum4, res_x, res_y), "srx_write_raw");
+}
+}  // namespace FileManager
+
+// ImageHandler::postProcessRaw (ImageProcessing.h:152-158) + the canvas store of GUI::commit_pixel (GUI.h:104-107)
+namespace ImageHandler {
+inline void postProcessRaw(const float* d_accum4, int res_x, int res_y, uint8_t* d_rgba8, int tonemap = SRX_TONEMAP_NONE) {
+    check(srx_post_process(d_accum4, res_x, res_y, tonemap, d_rgba8, nullptr), "srx_post_process");
+}
+}  // namespace ImageHandler
 
 }  // namespace spatialray
