@@ -681,6 +681,10 @@ struct Loader {
             for (size_t c = 0; ch && c < ch->size(); c++) {
                 auto it = node_lookup.find((int)ch->at(c).as_double());
                 if (it == node_lookup.end() || it->second.first != 1) continue;
+                // a node hierarchy is a forest (glTF 2.0, 3.5.2): a second parent or a cycle would make the walks below endless
+                if (objects[(size_t)it->second.second].parent >= 0) fail("glTF: a mesh node has two parents");
+                for (int up = kv.second.second; up >= 0; up = objects[(size_t)up].parent)
+                    if (up == it->second.second) fail("glTF: the node hierarchy has a cycle");
                 objects[(size_t)kv.second.second].children.push_back(it->second.second);
                 objects[(size_t)it->second.second].parent = kv.second.second;
             }

@@ -143,3 +143,32 @@ def test_transform_arithmetic_matches_reference_object_code():
     for i in range(n):
         assert np.array_equal(sro_gltf.q_multiply(a4[i], b4[i]).view(np.uint32), out[i].view(np.uint32))
         assert np.array_equal(sro_gltf.apply_rotation(v[i], a4[i]).view(np.uint32), r3[i].view(np.uint32))
+
+
+def test_malformed_files_fail_loudly(tmp_path):
+    """A cycle in the node hierarchy, an accessor beyond the buffer, an index beyond the vertices, a truncated file."""
+    import json, struct
+
+    def scene(mutate):
+        g = GlbWriter()
+        g.accessor(np.zeros((1, 3), np.float32), "VEC3")
+        tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.5]], np.float32)
+        g.js["meshes"].append({"primitives": [{"attributes": {"POSITION": g.accessor(tri, "VEC3")}, "indices": g.accessor(np.array([0, 1, 2], np.uint16), "SCALAR")}]})
+        g.js["nodes"] = [{"mesh": 0, "children": [1]}, {"mesh": 0}, {"camera": 0}]
+        g.js["cameras"].append({"type": "perspective", "perspective": {"aspectRatio": 1.0, "yfov": 0.7}})
+        mutate(g)
+        return g
+
+    def cyc(g): g.js["nodes"][1]["children"] = [0]
+    def far(g): g.js["accessors"][1]["count"] = 1000
+    def idx(g): g.bin[g.js["bufferViews"][g.js["accessors"][2]["bufferView"]]["byteOffset"]] = 9
+    for name, mut in (("cycle", cyc), ("accessor", far), ("index", idx)):
+        scene(mut).write(tmp_path / (name + ".glb"))
+        with pytest.raises(_lib.SrxError):
+            gltf.load_gltf_file(tmp_path / (name + ".glb"), 4, 4)
+    scene(lambda g: None).write(tmp_path / "ok.glb")
+    assert len(gltf.load_gltf_file(tmp_path / "ok.glb", 4, 4).tris) == 2
+    b = open(tmp_path / "ok.glb", "rb").read()
+    open(tmp_path / "cut.glb", "wb").write(b[:len(b) // 2])
+    with pytest.raises(_lib.SrxError):
+        gltf.load_gltf_file(tmp_path / "cut.glb", 4, 4)
