@@ -159,12 +159,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 }
 
 // ---------------------------------------------------------------- shade
+// Staging slots per wave for surviving children. A flush is one returning atomic on the queue counter plus the
+// write-out, and the wave stalls for it: with 128 slots (flush above 64) the shade kernel took 50.1 ms per 4 passes, with
+// 176 / 192 / 208 slots 41.4 / 41.1 / 40.9 ms, with 256 (LDS for 3 blocks per CU instead of 4) 43.6 ms.
+#ifndef SRX_STAGE
+#define SRX_STAGE 192
+#endif
 __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool live = idx < a.n;
-    __shared__ GRay s_stage[4][128];          // per-wave staging of surviving children (24 KB)
+    __shared__ GRay s_stage[4][SRX_STAGE];          // per-wave staging of surviving children (36 KB per block: 4 blocks = 16 waves per CU, what 116 VGPRs allow)
     __shared__ uint32_t s_wave_count[4];
     __shared__ uint32_t s_base[2];
     GRay* const stage = s_stage[threadIdx.x >> 6];
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
             }
         }
         // compaction: survivors are staged in this wave's LDS buffer (ballot + prefix count give the slot);
-        // the buffer is flushed to the queue with ONE reservation whenever it holds more than 64 rays
+        // the buffer is flushed to the queue with ONE reservation whenever a trip's 64 lanes might not fit any more
         const unsigned long long em = __ballot(emit);
         if (em) {
             if (emit) {
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
                 n_children++;
             }
             staged += (uint32_t)__popcll(em);
-            if (staged > 64u) {
+            if (staged > (uint32_t)(SRX_STAGE - 64)) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(a.out_count, staged);
                 base = (uint32_t)__shfl((int)base, 0, 64);
