@@ -16,8 +16,13 @@ OUT = os.path.join(HERE, "libsrx.so")
 # -ffp-contract=off: FMAs only where the kernels say __fmaf_rn (bit parity with the CPU path);
 # denormals are kept (no -fgpu-flush-denormals-to-zero); correctly rounded fp32 divide/sqrt (HIP default).
 # -fno-slp-vectorize: packed-f32 pairs (v_pk_fma_f32 + the v_mov shuffles that feed them) measured 4 % slower.
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared",
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC",
          "-fno-gpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# Per-file additions. srx_trace.hip: the traversal loop has wave-uniform branches (`if (ballot(...) != 0)`) around
+# divergent code; left unstructurized they cost 15 fewer v_mov per trip (closest hit 99.8 -> 95.8 ms, shadow
+# 52.6 -> 49.9 ms per 4 passes). The whole cast / shade test suite runs against the library built this way.
+EXTRA = {"srx_trace.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]}
+OBJ = os.path.join(HERE, "_obj")
 
 
 def needs_build():
@@ -32,11 +37,24 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc] + FLAGS + srcs + ["-o", OUT]
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(OBJ, src + ".o")
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((obj, cmd, subprocess.Popen(cmd)))       # one compiler process per translation unit, side by side
+    for obj, cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for obj, _, _ in jobs] + ["-o", OUT]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return OUT
 
 
