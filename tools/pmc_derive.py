@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Derives the figures of profiles/r01_pmc_summary.md from a pmc_summary.py text file and a kernel_stats.csv.
+Usage: pmc_derive.py <pmc_summary.txt> <kernel_stats_single_stream.csv> <passes in the stats run>"""
+import csv, json, re, sys
+from collections import defaultdict
+
+tot = defaultdict(float); disp = defaultdict(int)
+for line in open(sys.argv[1]):
+    m = re.match(r"(.*?)\s+(\S+)\s+total\s+(\S+)\s+per_dispatch\s+\S+\s+dispatches\s+(\d+)", line)
+    if m and not line.startswith("#"):
+        k = re.sub(r"<(\d), \d>", r"<\1>", m.group(1).strip().replace("void ", ""))     # fold the K variants of a mode
+        tot[(k, m.group(2))] += float(m.group(3)); disp[(k, m.group(2))] += int(m.group(4))
+ms = defaultdict(float)
+for r in csv.DictReader(open(sys.argv[2])):
+    k = re.sub(r"<(\d), \d>", r"<\1>", r["Name"].split("(")[0].replace("void ", ""))
+    ms[k] += float(r["TotalDurationNs"]) / 1e6 / int(sys.argv[3])
+out = {}
+for k in ("k_trace<0>", "k_trace<2>", "k_shade"):
+    g = lambda c: tot[(k, c)]
+    t = ms[k]; cyc = t * 1e-3 * 2.4e9
+    d = {"ms_per_pass": t, "launches": disp[(k, "SQ_WAVES")], "waves": g("SQ_WAVES"), "valu": g("SQ_INSTS_VALU"), "salu": g("SQ_INSTS_SALU"),
+         "vmem_rd": g("SQ_INSTS_VMEM_RD"), "lds": g("SQ_INSTS_LDS"),
+         "valu_busy": g("SQ_INSTS_VALU") / 1024 * 2 / cyc, "waves_per_simd": g("SQ_WAVE_CYCLES") * 4 / (cyc * 1024),
+         "cycles_per_wave": g("SQ_WAVE_CYCLES") * 4 / max(1, g("SQ_WAVES")),
+         "wait_inst_any": g("SQ_WAIT_INST_ANY") / max(1, g("SQ_WAVE_CYCLES")), "wait_any": g("SQ_WAIT_ANY") / max(1, g("SQ_WAVE_CYCLES")),
+         "l1_hit": 1 - g("TCP_TCC_READ_REQ_sum") / max(1, g("TCP_TOTAL_CACHE_ACCESSES_sum")), "l2_hit": g("TCC_HIT_sum") / max(1, g("TCC_REQ_sum")),
+         "l1_miss_latency_cycles": g("TCP_TCC_READ_REQ_LATENCY_sum") / max(1, g("TCP_TCC_READ_REQ_sum")),
+         "fetch_GB": g("FETCH_SIZE") * 1000 * 2 / 1e9, "fetch_TBps": g("FETCH_SIZE") * 1000 * 2 / (t * 1e-3) / 1e12,
+         "ta_busy": g("TA_TA_BUSY_sum") / 256 / cyc, "td_busy": g("TD_TD_BUSY_sum") / 256 / cyc,
+         "td_tc_stall_of_busy": g("TD_TC_STALL_sum") / max(1, g("TD_TD_BUSY_sum")),
+         "lds_bank_conflict": g("SQ_LDS_BANK_CONFLICT") / max(1, g("SQ_LDS_IDX_ACTIVE"))}
+    out[k] = d
+print(json.dumps(out, indent=1))
