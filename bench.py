@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tris", type=int, default=262144)
     ap.add_argument("--res", type=str, default="1920x1080")
-    ap.add_argument("--ray-capacity", type=int, default=1 << 28, help="ray queue slots (35 GB of queues at 2^28: a whole 1080p generation fits one launch)")
+    ap.add_argument("--ray-capacity", type=int, default=1 << 29, help="ray queue slots (132 B each: 71 GB of the 288 GB at 2^29, so a whole 1080p generation fits one launch even in the transmissive interior)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="1920x1080", help="centre crop of the frame timed on the host cores")
     ap.add_argument("--cpu-threads", type=int, default=0)
