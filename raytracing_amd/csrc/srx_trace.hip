@@ -408,7 +408,8 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
     // a launch that cannot fill the chip's 8 192 wave slots (256 CUs x 32) with K rays per octet takes fewer: more waves,
     // each a shorter serial chain (the last generations of a pass are launches of a few thousand rays)
     while (k > 1 && (uint64_t)a.n < 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
-    if (const char* e = getenv("SRX_RAYS_PER_OCTET")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) k = v; }   // experiments
+    static const int forced = [] { const char* e = getenv("SRX_RAYS_PER_OCTET"); return e ? atoi(e) : 0; }();   // experiments
+    if (forced == 1 || forced == 2 || forced == 4) k = forced;
     const uint32_t rays_per_block = SRX_OCTETS_PER_BLOCK * (uint32_t)k;
     uint32_t blocks = (a.n + rays_per_block - 1) / rays_per_block;
     blocks = (blocks + 7u) & ~7u;   // multiple of 8 so the XCD map covers every logical block exactly once
