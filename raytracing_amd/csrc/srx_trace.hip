@@ -264,6 +264,10 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     __builtin_amdgcn_wave_barrier();
 
     while (__builtin_amdgcn_ballot_w64(sp >= 0) != 0ull) {
+        // A wave that is about to pop and request its next lines goes first, one that has its data and computes goes
+        // last: the sooner a trip's loads are out, the more of their latency the other waves cover (+0.4 %; the
+        // opposite order costs 4 %).
+        __builtin_amdgcn_s_setprio(3);
         // pop until an entry survives the distance cull (Core.h:63-68)
         uint32_t link = 0;
         bool go = false;
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             const char* const rec = sc.geom + (size_t)off;
             const float4 A = *(const float4*)rec;
             const float3 B = *(const float3*)(rec + 128);   // 12 of the slot's 16 bytes: {max.y, max.z, link} / {e1.y, e1.z, e2.x}
+            __builtin_amdgcn_s_setprio(0);
             if (!leaf) {
                 n_nodes++;
                 bool may_hit;
