@@ -185,6 +185,10 @@ def main():
     # steps = sample passes; B of them travel through the same kernel launches (same samples as one call per pass)
     B = args.passes_per_call if args.passes_per_call > 0 else max(world, args.share_of)
     B = max(1, min(B, ((1 << 24) - 1) // (W * H)))
+    # size the renderer's per-pass sample buffers for B passes before anything is timed (4 rows into scratch framebuffers)
+    scratch = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
+    RE.trace_pass(cam, (0, 0, W, min(H, tiles.TILE)), 0, args.seed, scratch, scratch.clone(), ray_capacity=args.ray_capacity, n_passes=B)
+    del scratch
     for p in range(0, args.warmup, B):
         RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share, n_passes=min(B, args.warmup - p))
     if world > 1:
