@@ -203,6 +203,35 @@ def test_several_passes_in_one_call_equal_one_call_per_pass(loaded):
         RE.trace_pass(cam, (0, 0, w, h), 0, 77, many[0], many[1], n_passes=0)
 
 
+def test_shadow_stream_on_and_off_give_the_same_pass(loaded, monkeypatch):
+    """The shadow kernels run on a second stream beside the next generation's closest-hit kernel (two shadow queues,
+    event-ordered); SRX_SHADOW_STREAM=0 puts them back on the main stream. Same rays, same counters, same image up
+    to the order of the float atomics."""
+    import torch
+    from raytracing_amd import engine
+    name, desc, RE, S = loaded
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SRX_SHADOW_STREAM", flag)
+        RE2 = engine.RayEngine(0)
+        RE2.load_scene(RE.data)
+        acc = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+        aux = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+        cs = [RE2.trace_pass(cam, (0, 0, w, h), p, 31, acc, aux, ray_capacity=1 << 16) for p in range(2)]   # small queue: many batches
+        torch.cuda.synchronize()
+        out.append((acc.cpu().numpy(), aux.cpu().numpy(), cs))
+        RE2.close()
+    (a1, x1, c1), (a0, x0, c0) = out
+    for ca, cb in zip(c1, c0):
+        for k in ("rays_processed", "shadows_cast", "nodes", "packets", "shadow_nodes", "shadow_packets", "hits"):
+            assert int(ca[k]) == int(cb[k]), k
+    assert np.array_equal(a1[:, 3], a0[:, 3]) and np.array_equal(x1[:, 3], x0[:, 3])
+    assert np.allclose(a1[:, :3], a0[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
+    assert np.allclose(x1[:, :3], x0[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
+
+
 def test_converged_image_matches_reference_rng_estimator(tables):
     """Property test at image level: the GPU (keyed per-ray streams, throughput carried down the path, float atomics)
     and the oracle in REFERENCE mode (one sequential xoshiro stream, recursion multiplying on the way back,
