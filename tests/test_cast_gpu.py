@@ -163,6 +163,25 @@ def test_multi_packet_leaves_and_ties(tables):
     RE.close()
 
 
+def test_every_rays_per_octet_choice(tables):
+    """The launcher takes 1, 2 or 4 rays per octet by the size of the launch (and by the LDS the tree's stack needs):
+    100 000 / 200 000 / 300 000 rays run the three kernel instances; all must equal the oracle bit for bit."""
+    from oracle import sro
+    from raytracing_amd import engine, scenes
+    desc = scenes.soup(3000, seed=12)
+    PS = engine.package(desc, tables=tables)
+    S = sro.OracleScene(desc, tables=tables)
+    RE = engine.RayEngine(0)
+    RE.load_scene(PS)
+    for n in (100_000, 200_000, 300_000):
+        org, dirs = random_rays(n, seed=n)
+        g, gc = RE.execute_ray_cast(org, dirs)
+        c, cc = S.cast_closest(org, dirs)
+        _assert_hits_equal(g, c)
+        assert int(gc[0]) == int(cc[0]) and int(gc[1]) == int(cc[1]) - int(cc[3])
+    RE.close()
+
+
 def test_million_triangle_scene(tables):
     """Scale case (towards BASELINE configs[3]): 1 M triangles, 75 MB of nodes + packets — past the L2s, byte offsets
     beyond 2^26; the packages of the threaded product builder and of the oracle must be identical, then the casts."""
