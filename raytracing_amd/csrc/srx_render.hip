@@ -56,6 +56,8 @@ struct srx_renderer {
 
 extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_renderer** out) {
     if (!scene || !out) SRX_FAIL("srx_renderer_create: null argument");
+    if (scene->g.n_packets > 0 && (scene->g.n_materials == 0 || scene->g.n_tris == 0))
+        SRX_FAIL("srx_renderer_create: the scene has no materials or no shading triangles (it can only be cast against)");
     if (ray_capacity < 64) SRX_FAIL("srx_renderer_create: ray_capacity must be at least 64");
     if (ray_capacity > 0xFFFFFFF0ull) SRX_FAIL("srx_renderer_create: ray_capacity must fit 32 bits");
     srx_renderer* r = new srx_renderer();

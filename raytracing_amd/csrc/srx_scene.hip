@@ -115,6 +115,8 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
             if ((leaf == 0 && idx >= desc->n_nodes) || (leaf > 0 && ((uint64_t)idx + leaf > desc->n_packets))) {
                 srx_scene_destroy(s); SRX_FAIL("srx_scene_create: node child index out of range");
             }
+            // children are appended after their parent (BVH.h:1008-1072): anything else is not a tree this traversal ends on
+            if (leaf == 0 && idx != 0 && idx <= i) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: a node's child must have a larger index than the node"); }
             uint32_t link = 0;                                        // unused slot (BVH.h:890-895)
             if (leaf == 0 && idx != 0) link = 2u * idx;
             if (leaf > 0) {
@@ -148,6 +150,14 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     for (uint32_t i = 0; i < desc->n_packets; i++) {
         const uint8_t* pk = rp + (size_t)i * SRX_REF_PACKET_BYTES;
         const int32_t index = (int32_t)rdu(pk, 416);
+        // what a hit hands to the shading kernel must exist (empty lanes are never hit: det = 0, Primitives.h:159-202)
+        const int size = std::min(8, (int)(int8_t)pk[420]);
+        for (int k = 0; k < size; k++) {
+            const uint32_t mat = rdu(pk, 384 + 4 * k);
+            if ((desc->n_materials > 0 && mat >= desc->n_materials) || (desc->n_tris > 0 && (index < 0 || (uint64_t)index + k >= desc->n_tris))) {
+                srx_scene_destroy(s); SRX_FAIL("srx_scene_create: packet material or triangle index out of range");
+            }
+        }
         for (int k = 0; k < 8; k++) {
             const float p1x = rdf(pk, 0 + 4 * k), p1y = rdf(pk, 32 + 4 * k), p1z = rdf(pk, 64 + 4 * k);
             const float e1x = rdf(pk, 96 + 4 * k), e1y = rdf(pk, 128 + 4 * k), e1z = rdf(pk, 160 + 4 * k);

@@ -182,6 +182,49 @@ def test_every_rays_per_octet_choice(tables):
     RE.close()
 
 
+def test_malformed_package_is_refused(tables):
+    """srx_scene_create checks what the kernels rely on before anything is uploaded: a child link that points back
+    (a cycle would never end on the GPU), a child or packet range past the arrays, a packet whose material or triangle
+    index the shading kernel could not fetch; and a renderer is refused on a scene without materials."""
+    import copy
+    from raytracing_amd import engine, scenes, _lib
+    desc = scenes.soup(3000, seed=4)
+    PS = engine.package(desc, tables=tables)
+    nodes = PS.avx_bvh.view(np.uint32).reshape(len(PS.avx_bvh), 72)     # leaf_size[8] at word 48, indexes[8] at word 56
+    inner = [(i, k) for i in range(len(nodes)) for k in range(8) if nodes[i, 48 + k] == 0 and nodes[i, 56 + k] != 0]
+    leafs = [(i, k) for i in range(len(nodes)) for k in range(8) if nodes[i, 48 + k] != 0]
+    assert inner and leafs
+    RE = engine.RayEngine(0)
+
+    def refused(mutate, what):
+        bad = copy.deepcopy(PS)
+        mutate(bad)
+        with pytest.raises(_lib.SrxError, match=what):
+            RE.load_scene(bad)
+
+    i, k = inner[-1]
+    def back_link(b): b.avx_bvh.view(np.uint32).reshape(-1, 72)[i, 56 + k] = i
+    refused(back_link, "larger index")
+    def far_link(b): b.avx_bvh.view(np.uint32).reshape(-1, 72)[i, 56 + k] = len(nodes)
+    refused(far_link, "out of range")
+    li, lk = leafs[0]
+    def far_leaf(b): b.avx_bvh.view(np.uint32).reshape(-1, 72)[li, 56 + lk] = len(b.avx_tri_data)
+    refused(far_leaf, "out of range")
+    def bad_material(b): b.avx_tri_data.view(np.uint32).reshape(-1, 112)[0, 96] = len(b.materials)       # materials[8] at byte 384
+    refused(bad_material, "packet material or triangle index")
+    def bad_index(b): b.avx_tri_data.view(np.int32).reshape(-1, 112)[0, 104] = len(b.tri_data)           # index at byte 416
+    refused(bad_index, "packet material or triangle index")
+    # casts work on a scene without materials; shading it is refused when the renderer is made
+    bare = copy.deepcopy(PS)
+    bare.materials = bare.materials[:0]
+    RE.load_scene(bare)
+    org, dirs = random_rays(1000, seed=1)
+    RE.execute_ray_cast(org, dirs)
+    with pytest.raises(_lib.SrxError, match="no materials"):
+        RE.process_ray(org[:4], dirs[:4], np.arange(4, dtype=np.uint64))
+    RE.close()
+
+
 def test_million_triangle_scene(tables):
     """Scale case (towards BASELINE configs[3]): 1 M triangles, 75 MB of nodes + packets — past the L2s, byte offsets
     beyond 2^26; the packages of the threaded product builder and of the oracle must be identical, then the casts."""
