@@ -21,9 +21,11 @@
 #define SRX_TRACE_THREADS 64
 #endif
 #define SRX_OCTETS_PER_BLOCK (SRX_TRACE_THREADS / 8)
-// Rays per octet: an octet works through K rays one after the other, so a wave carries 8 K rays and ends when its
-// slowest OCTET ends: the sum of K ray lengths varies less than one length (K = 4 saves 7 % of the wave-trips). All K set-ups (the IEEE divides of Core.h:53-54) are computed up
-// front, one ray per lane, and parked in LDS; switching rays costs three LDS reads.
+// Rays per octet: a wave carries 8 K rays and its octets work through them one after the other, so it ends when the
+// pool is used up rather than with its longest single ray (K = 4 saves 7 % of the wave-trips with a fixed four rays per
+// octet; an octet that ends a ray takes the next ray nobody has taken, not the next of its own four: another 2 %). All
+// 8 K set-ups (the IEEE divides of Core.h:53-54) are computed up front, one ray per lane, and parked in LDS; switching
+// rays costs three LDS reads.
 // Measured (bench workload, before K became a template parameter): K = 1 / 2 / 3 / 4 / 5 / 6 / 8 -> 1002 / 1007 / 1031 / 1041 / 1044 / 944 / 950 Mrays/s (the
 // shadow kernel gains 12 %, the closest-hit kernel nothing; from K = 6 the LDS footprint costs a wave per SIMD).
 // K is a template parameter: the launcher takes the largest of 4 / 2 / 1 whose LDS footprint (64 B x stack depth +
@@ -201,12 +203,14 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             s_pt[sub * SRX_OCTETS_PER_BLOCK + oct] = spt;
         }
     }
-    // rays of this octet that exist: indices grow with j, so they are j = 0 .. cnt-1
-    int cnt = 0;
-    if (lblock < nblk && ray0 < n_rays) cnt = (int)min((uint32_t)K, (n_rays - ray0 + SRX_OCTETS_PER_BLOCK - 1) / SRX_OCTETS_PER_BLOCK);
-    int cur = 0;
+    // the block's rays that exist are j = 0 .. block_rays-1 (ray j was set up by lane j / 8 of octet j % 8); octet o starts
+    // with ray o, `next_j` (wave-uniform) is the first ray no octet has taken yet
+    int block_rays = 0;
+    if (lblock < nblk && lblock * SRX_RAYS_PER_BLOCK < n_rays) block_rays = (int)min(SRX_RAYS_PER_BLOCK, n_rays - lblock * SRX_RAYS_PER_BLOCK);
+    int cur = oct < block_rays ? oct : -1;   // the ray this octet works on, -1 = none
+    int next_j = SRX_OCTETS_PER_BLOCK;
     uint32_t ray = ray0;
-    const bool live = cnt > 0;
+    const bool live = cur >= 0;
     __builtin_amdgcn_wave_barrier();
 
     // per ray in registers: what the node test needs (1/d, -o/d); origin and direction stay in LDS and are read by the
@@ -214,14 +218,14 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     f3 inv, fused;
     const float4* ray_setup = s_setup;
     float pt2 = 0.0f, npt = 0.0f;
-    auto load_ray = [&](int j) {
-        ray_setup = s_setup + ((size_t)j * SRX_OCTETS_PER_BLOCK + oct) * 3;
+    auto load_ray_j = [&](int j) {
+        ray_setup = s_setup + (size_t)j * 3;
         const float2 r1 = *(const float2*)((const char*)ray_setup + 24);
         const float4 r2 = ray_setup[2];
-        const float pt = s_pt[j * SRX_OCTETS_PER_BLOCK + oct];
+        const float pt = s_pt[j];
         pt2 = pt + pt; npt = -pt; inv = f3(r1.x, r1.y, r2.x); fused = f3(r2.y, r2.z, r2.w);
     };
-    load_ray(0);
+    load_ray_j(oct);
 
     float best_t = SRX_MISS_DISTANCE;
     uint32_t n_nodes = 0, n_packets = 0;
@@ -360,24 +364,32 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             }
         }
         if (K > 1) {
-            // an octet whose ray has ended takes its next one: result out, set-up in from LDS, stack = {root}
-            const bool next_ray = sp < 0 && cur + 1 < cnt;
-            if (__builtin_amdgcn_ballot_w64(next_ray) != 0ull) {
-                if (next_ray) {
+            // An octet whose ray has ended writes its result and takes the next ray of the wave's block that nobody
+            // has taken yet (the K x 8 rays were all set up into LDS at the start): the wave ends when the block's rays
+            // are used up, not when the octet with the most work of a fixed four ends.
+            const bool ended = sp < 0 && cur >= 0;
+            const unsigned long long eb = __builtin_amdgcn_ballot_w64(ended && sub == 0);
+            if (eb != 0ull) {
+                if (ended) {
                     finish(ray);
-                    cur++;
-                    ray += SRX_OCTETS_PER_BLOCK;
-                    load_ray(cur);
-                    best_t = SRX_MISS_DISTANCE;
-                    sp = 0;
-                    if (sub == 0) s_stack[oct] = 0ull;
+                    const int j = next_j + __popcll(eb & ((1ull << oct_shift) - 1ull));
+                    cur = -1;
+                    if (j < block_rays) {
+                        cur = j;
+                        ray = lblock * SRX_OCTETS_PER_BLOCK * K + (uint32_t)j;
+                        load_ray_j(j);
+                        best_t = SRX_MISS_DISTANCE;
+                        sp = 0;
+                        if (sub == 0) s_stack[oct] = 0ull;
+                    }
                 }
+                next_j += __popcll(eb);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
 
-    if (live) finish(ray);
+    if (K == 1 && live) finish(ray);
     if (a.counters) {
         // one atomic per wave and counter, spread over replicated slots (a single hot word serialises the chip)
         uint32_t wn = (live && sub == 0) ? n_nodes : 0u, wp = (live && sub == 0) ? n_packets : 0u;
