@@ -176,6 +176,7 @@ def main():
     share = (tiles.TILE, rank, world) if args.share_of <= 1 else (tiles.TILE, 0, args.share_of)
     accum = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
     aux = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
+    my_rows = tiles.interleaved_rows(rank, world, H).cuda()
 
     def barrier():
         if world > 1:
@@ -193,10 +194,9 @@ def main():
         RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share, n_passes=min(B, args.warmup - p))
     if world > 1:
         # warm-up of the two exchanges as well (communicator set-up, index tensors); they only fill in the other ranks' rows
-        sums, mins = tiles.rows_noise_stats(accum, aux, H, W, tiles.interleaved_rows(rank, world, H))
+        sums, mins = tiles.rows_noise_stats(accum, aux, H, W, my_rows)
         tiles.allreduce_noise_stats(sums, mins)
-        tiles.gather_framebuffer_interleaved(accum, H, W)
-        tiles.gather_framebuffer_interleaved(aux, H, W)
+        tiles.gather_framebuffer_interleaved([accum, aux], H, W)
     barrier()
     t0 = time.perf_counter()
     tot = {}
@@ -207,10 +207,9 @@ def main():
             tot[k] = tot.get(k, 0) + v
     if world > 1:
         # the two exchange steps: noise statistics all-reduce (KBs) and framebuffer all-gather over xGMI
-        sums, mins = tiles.rows_noise_stats(accum, aux, H, W, tiles.interleaved_rows(rank, world, H))
+        sums, mins = tiles.rows_noise_stats(accum, aux, H, W, my_rows)
         tiles.allreduce_noise_stats(sums, mins)
-        tiles.gather_framebuffer_interleaved(accum, H, W)
-        tiles.gather_framebuffer_interleaved(aux, H, W)
+        tiles.gather_framebuffer_interleaved([accum, aux], H, W)
     barrier()
     dt = time.perf_counter() - t0
 

@@ -81,38 +81,55 @@ def _gather_slabs(buf, height, width, tile):
     return buf
 
 
-def gather_framebuffer_interleaved(buf: torch.Tensor, height: int, width: int, tile: int = TILE):
-    """In-place all-gather of a (height*width, C) framebuffer whose rank-owned interleaved rows are valid.
-    Each rank packs its rows, one all-gather moves the packed shares (padded to the largest), every rank unpacks."""
-    if not _is_dist():
+def gather_framebuffer_interleaved(buf, height: int, width: int, tile: int = TILE):
+    """In-place all-gather of (height*width, C) framebuffers whose rank-owned interleaved rows are valid: `buf` is one
+    tensor or a list of tensors of the same shape and dtype (main and aux buffer), which then travel in ONE collective.
+    Each rank packs its rows, one all-gather moves the packed shares (padded to the largest), every rank unpacks with
+    one indexed copy."""
+    bufs = list(buf) if isinstance(buf, (list, tuple)) else [buf]
+    if not _is_dist() or not bufs:
         return buf
-    return _host_staged(_gather_interleaved, buf, height, width, tile)
-
-
-_OWNED = {}
-
-
-def _owned_rows(world, height, tile, device):
-    """Row indices of every rank on `device`, built once per layout (the gather sits inside timed regions)."""
-    key = (world, height, tile, str(device))
-    if key not in _OWNED:
-        _OWNED[key] = [interleaved_rows(r, world, height, tile).to(device) for r in range(world)]
-    return _OWNED[key]
-
-
-def _gather_interleaved(buf, height, width, tile):
-    world, rank = dist.get_world_size(), dist.get_rank()
-    view = buf.view(height, -1)
-    owned = _owned_rows(world, height, tile, buf.device)
-    most = max(len(o) for o in owned)
-    mine = torch.zeros((most, view.shape[1]), dtype=buf.dtype, device=buf.device)
-    mine[: len(owned[rank])] = view[owned[rank]]
-    everyone = torch.empty((world * most, view.shape[1]), dtype=buf.dtype, device=buf.device)
-    dist.all_gather_into_tensor(everyone, mine)
-    for r in range(world):
-        if r != rank and len(owned[r]):
-            view[owned[r]] = everyone[r * most: r * most + len(owned[r])]
+    if bufs[0].is_cuda and dist.get_backend() == "gloo":      # gloo moves host memory only (CPU tests, rehearsals)
+        hosts = [b.cpu() for b in bufs]
+        _gather_interleaved(hosts, height, width, tile)
+        for b, h in zip(bufs, hosts):
+            b.copy_(h)
+    else:
+        _gather_interleaved(bufs, height, width, tile)
     return buf
+
+
+_LAYOUT = {}
+
+
+def _interleaved_layout(world, height, tile, device):
+    """Per layout, built once (the gather sits inside timed regions): this and every rank's row indices, and for the
+    unpack the frame rows in the order the gathered buffer holds them with their positions in it (padding skipped)."""
+    key = (world, height, tile, str(device))
+    if key not in _LAYOUT:
+        owned = [interleaved_rows(r, world, height, tile) for r in range(world)]
+        most = max(len(o) for o in owned)
+        dst = torch.cat(owned)
+        src = torch.cat([r * most + torch.arange(len(o)) for r, o in enumerate(owned)])
+        _LAYOUT[key] = ([o.to(device) for o in owned], most, dst.to(device), src.to(device))
+    return _LAYOUT[key]
+
+
+def _gather_interleaved(bufs, height, width, tile):
+    world, rank = dist.get_world_size(), dist.get_rank()
+    views = [b.view(height, -1) for b in bufs]
+    cols = views[0].shape[1]
+    owned, most, dst, src = _interleaved_layout(world, height, tile, bufs[0].device)
+    nb = len(views)
+    # [rank][buffer][row]: one rank's share of every buffer is contiguous
+    mine = torch.zeros((nb, most, cols), dtype=bufs[0].dtype, device=bufs[0].device)
+    for i, v in enumerate(views):
+        mine[i, : len(owned[rank])] = v[owned[rank]]
+    everyone = torch.empty((world, nb, most, cols), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(everyone.view(world * nb * most, cols), mine.view(nb * most, cols))
+    for i, v in enumerate(views):
+        v[dst] = everyone[:, i].reshape(world * most, cols)[src]
+    return bufs
 
 
 def allreduce_noise_stats(sums: torch.Tensor, min_samples: torch.Tensor):

@@ -59,6 +59,12 @@ def _worker_interleaved(rank, world, port, H, W, q):
     buf.view(H, W * 4)[rows] = full.view(H, W * 4)[rows]
     tiles.gather_framebuffer_interleaved(buf, H, W)
     ok_gather = bool(torch.equal(buf, full))
+    # main and aux buffer in one collective
+    two = [torch.zeros_like(full), torch.zeros_like(full)]
+    for k, t in enumerate(two):
+        t.view(H, W * 4)[rows] = (full + 1000.0 * k).view(H, W * 4)[rows]
+    tiles.gather_framebuffer_interleaved(two, H, W)
+    ok_gather = ok_gather and bool(torch.equal(two[0], full)) and bool(torch.equal(two[1], full + 1000.0))
     acc = torch.rand(H * W, 4, generator=torch.Generator().manual_seed(1)) + 0.1
     aux = torch.rand(H * W, 4, generator=torch.Generator().manual_seed(2)) + 0.1
     acc[:, 3] = 7 + rank
