@@ -136,6 +136,9 @@ int srx_scene_create(const srx_scene_desc* desc, srx_scene** out);
 void srx_scene_destroy(srx_scene* scene);
 /* worst-case traversal stack depth of this scene's tree (the reference reserves 256, Scene.h:181) */
 int srx_scene_stack_bound(const srx_scene* scene);
+/* Times a traversal wave moved part of its stack from on-chip memory to the scene's overflow areas so far (deep trees
+ * keep only the top of the stack on chip; no counterpart in the reference, whose stack is a 256-entry array). */
+int64_t srx_scene_stack_spills(const srx_scene* scene);
 
 /* ---- casts: replace `RayEngine::execute_ray_cast(XYZ&, const XYZ&)` (Core.h:346) over a batch.
  * Host-pointer form copies in and out; the _device form takes device pointers and a hipStream_t

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SRX_LIB", os.path.join(HERE, "libsrx.so"))
 EXPORTS = [
     "srx_last_error", "srx_init",
     "srx_package_create", "srx_package_get", "srx_package_destroy", "srx_build_tables",
-    "srx_scene_create", "srx_scene_destroy", "srx_scene_stack_bound",
+    "srx_scene_create", "srx_scene_destroy", "srx_scene_stack_bound", "srx_scene_stack_spills",
     "srx_cast_closest", "srx_cast_closest_device", "srx_cast_shadow", "srx_cast_shadow_device",
     "srx_renderer_create", "srx_renderer_destroy", "srx_renderer_set_timing",
     "srx_trace_pass", "srx_trace_pass_interleaved", "srx_trace_passes_interleaved", "srx_trace_pass_adaptive", "srx_process_rays", "srx_camera_rays",
@@ -74,6 +74,7 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         L.srx_last_error.restype = C.c_char_p
+        L.srx_scene_stack_spills.restype = C.c_int64
         _LIB = L
     return _LIB
 

@@ -35,6 +35,8 @@
 #define SRX_LINK_LINE_MASK 0x01FFFFFFu       // 2^25 lines of 128 B = 4 GB of nodes + packets
 #define SRX_LINK_MORE_SHIFT 25               // bits 25..29: packets of the same leaf after this one
 #define SRX_LINK_MORE_MAX 31u
+#define SRX_SPILL_SLOTS 16384u               // > 8 192 = the wave slots of the chip: a free area always exists
+#define SRX_SPILL_MIN_LDS_DEPTH 16           // half the LDS part moves at a time and a node pushes up to 8 entries
 #define SRX_LINK_EXT 0x40000000u             // leaf child whose reference box = tight planes stored here, grown to the origin
 
 struct GNode { float4 a[8]; float4 b[8]; };
@@ -80,7 +82,11 @@ struct GScene {
     uint32_t n_nodes, n_packets, n_tris, n_materials, n_textures, n_suns;
     int max_generations;
     int bounce_count[32];         // int(monte_carlo_max * pow(modifier, g)), host-computed (Core.h:428)
-    int stack_depth;              // LDS entries per octet (worst-case bound of this tree)
+    int stack_depth;              // worst-case number of live traversal-stack entries of this tree (per ray)
+    // Overflow of the traversal stack when a launch keeps fewer than stack_depth entries per octet in LDS (deep
+    // trees): SRX_SPILL_SLOTS areas of 8 x stack_depth entries, one per wave that ever spills, claimed with an atomic.
+    unsigned long long* spill_area;
+    uint32_t* spill_ctl;          // [0] claim cursor, [1] error flag (no free area), [2] spills so far, [16 + i] area i taken
     float filter_pad;             // leaf filter: planes are pushed out by this distance (1e-4 of the scene's size)
 };
 

@@ -26,6 +26,8 @@ void srx_set_error(const std::string& s);
 // reference record layouts (byte offsets from SURVEY §8a: a2, a5, a11)
 enum { SRX_REF_NODE_BYTES = 288, SRX_REF_PACKET_BYTES = 448, SRX_REF_TRI_BYTES = 196 };
 
+int srx_scene_check_spill(const struct srx_scene* scene);   // srx_scene.hip: 1 (+ error text) if a traversal wave found no overflow area
+
 struct srx_scene {
     GScene g;                         // device pointers + parameters, passed by value to kernels
     int device = 0;

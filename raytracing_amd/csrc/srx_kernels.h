@@ -14,6 +14,7 @@ struct TraceArgs {
     unsigned long long* counters;          // [0] node tests, [1] packet tests (of slot 0)
     uint32_t counter_slot_mask;            // counters are replicated in (mask+1) slots to spread the atomics ...
     uint32_t counter_slot_stride;          // ... slot s starts at counters + s*stride (u64 units); host sums the slots
+    int lds_depth;                         // set by srx_launch_trace: stack entries per octet kept in LDS (<= GScene::stack_depth)
 };
 
 // mode 0: closest hit; 1: shadow (API form, writes lit[]); 2: shadow (renderer queue form, adds lit contributions)

@@ -261,7 +261,7 @@ int end_call(srx_renderer* r, srx_counters* out) {
     r->acc.hits = c[CTR_HITS]; r->acc.texels = c[CTR_TEXELS]; r->acc.pdf_lookups = c[CTR_PDF];
     r->acc.diffuses_cast = c[CTR_CHILDREN];
     if (out) *out = r->acc;
-    return 0;
+    return srx_scene_check_spill(r->scene);
 }
 
 }  // namespace

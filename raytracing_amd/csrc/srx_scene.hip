@@ -255,6 +255,18 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
     const int bound = stack_bound(rn, desc->n_nodes);
     if (bound > 256) { srx_scene_destroy(s); SRX_FAIL("srx_scene_create: tree needs a traversal stack deeper than the reference's 256 entries (Scene.h:181)"); }
     g.stack_depth = std::max(bound, 2);
+    if (g.stack_depth > SRX_SPILL_MIN_LDS_DEPTH) {
+        // overflow areas of the traversal stack (srx_trace.hip): used by launches that keep fewer than `bound` entries
+        // per octet in LDS
+        const size_t area_bytes = (size_t)SRX_SPILL_SLOTS * 8 * (size_t)g.stack_depth * sizeof(unsigned long long);
+        const size_t ctl_bytes = (size_t)(16 + SRX_SPILL_SLOTS) * sizeof(uint32_t);
+        void *area = nullptr, *ctl = nullptr;
+        hipError_t e = hipMalloc(&area, area_bytes);
+        if (e == hipSuccess) { s->allocations.push_back(area); e = hipMalloc(&ctl, ctl_bytes); }
+        if (e == hipSuccess) { s->allocations.push_back(ctl); e = hipMemset(ctl, 0, ctl_bytes); }
+        if (e != hipSuccess) { srx_scene_destroy(s); SRX_FAIL(std::string("srx_scene_create: stack overflow areas: ") + hipGetErrorString(e)); }
+        g.spill_area = (unsigned long long*)area; g.spill_ctl = (uint32_t*)ctl;
+    }
     *out = s;
     return 0;
 }
@@ -266,6 +278,23 @@ extern "C" void srx_scene_destroy(srx_scene* scene) {
 }
 
 extern "C" int srx_scene_stack_bound(const srx_scene* scene) { return scene ? scene->g.stack_depth : -1; }
+
+// Called where a call has waited for its traversal kernels anyway: did a wave find no overflow area for its stack?
+int srx_scene_check_spill(const srx_scene* scene) {
+    if (!scene->g.spill_ctl) return 0;
+    uint32_t flag = 0;
+    SRX_HIP(hipMemcpy(&flag, scene->g.spill_ctl + 1, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) SRX_FAIL("srx: a traversal wave found no free stack overflow area; results of this call are incomplete");
+    return 0;
+}
+
+extern "C" int64_t srx_scene_stack_spills(const srx_scene* scene) {
+    if (!scene) return -1;
+    if (!scene->g.spill_ctl) return 0;
+    uint32_t n = 0;
+    if (hipMemcpy(&n, scene->g.spill_ctl + 2, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)n;
+}
 
 // ---------------------------------------------------------------- casts
 extern "C" int srx_cast_closest_device(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, srx_hit* d_hits,
@@ -318,7 +347,7 @@ extern "C" int srx_cast_closest(srx_scene* scene, const float* org3, const float
     SRX_HIP(hipMemcpy(hits, h.p, (size_t)n * sizeof(srx_hit), hipMemcpyDeviceToHost));
     if (advanced_org3) SRX_HIP(hipMemcpy(advanced_org3, adv.p, (size_t)n * 12, hipMemcpyDeviceToHost));
     if (counters2) SRX_HIP(hipMemcpy(counters2, c.p, 16, hipMemcpyDeviceToHost));
-    return 0;
+    return srx_scene_check_spill(scene);
 }
 
 extern "C" int srx_cast_shadow(srx_scene* scene, const float* org3, const float* dir3, uint32_t n, uint8_t* lit) {
@@ -335,5 +364,5 @@ extern "C" int srx_cast_shadow(srx_scene* scene, const float* org3, const float*
     SRX_HIP(srx_launch_trace(1, scene->g, a, 0));
     SRX_HIP(hipDeviceSynchronize());
     SRX_HIP(hipMemcpy(lit, l.p, n, hipMemcpyDeviceToHost));
-    return 0;
+    return srx_scene_check_spill(scene);
 }

@@ -10,7 +10,8 @@
 // lane id in their low 3 bits, so they are distinct and rank == position after the reference's
 // insertion sort. The traversal stack lives in LDS, one 8-byte (link, tmin) column per octet,
 // interleaved so the 8 octets of a wave hit distinct banks; its depth is the exact worst case of the
-// scene's tree, computed on the host (the reference reserves 256 entries, Scene.h:181).
+// scene's tree, computed on the host (the reference reserves 256 entries, Scene.h:181), or, for trees
+// too deep for that, 24 entries backed by an overflow area in memory (template parameter SPILL).
 // Bound: HBM/L2 gather bandwidth + latency (no MFMA work here); see DESIGN.md.
 #include "srx_kernels.h"
 #include <cstdlib>
@@ -28,11 +29,18 @@
 // rays costs three LDS reads.
 // Measured (bench workload, before K became a template parameter): K = 1 / 2 / 3 / 4 / 5 / 6 / 8 -> 1002 / 1007 / 1031 / 1041 / 1044 / 944 / 950 Mrays/s (the
 // shadow kernel gains 12 %, the closest-hit kernel nothing; from K = 6 the LDS footprint costs a wave per SIMD).
-// K is a template parameter: the launcher takes the largest of 4 / 2 / 1 whose LDS footprint (64 B x stack depth +
+// K is a template parameter: the launcher takes the largest of 4 / 2 / 1 (8 in the SPILL form) whose LDS footprint (64 B x stack depth +
 // 128 + 416 K bytes per wave) still lets 32 waves share a CU's 160 KB, because near 8 waves per SIMD the kernel's time
 // goes 1:1 with the waves in flight. Results do not depend on K.
 #define SRX_RAYS_PER_OCTET_MAX 4
 #define SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY 5120u
+// Trees deeper than 52 (no room for the whole stack in LDS at 4 rays per octet and 32 waves per CU): 24 entries per
+// octet in LDS, the rest in the overflow area, and the LDS this frees goes to a pool of 8 rays per octet (5 024 B per
+// wave). On the bench scene (depth 47, stack wholly in LDS: 1404 Mrays/s on one stream) this form measured 1411 with 8
+// rays per octet and 1370 with 4: the overflow checks cost the closest-hit kernel 2 % and the shadow kernel 5 %, the
+// larger pool gives 3 % back; it is used where the plain form would have to halve the rays per octet instead.
+#define SRX_SPILL_LDS_DEPTH 24
+#define SRX_RAYS_PER_OCTET_SPILL 8
 
 
 // ---- cross-lane helpers inside an octet, all DPP (no LDS crossbar): quad_perm for lane^1, ^2, ^3 and
@@ -143,13 +151,16 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float3 B, co
 }
 
 // MODE 0: closest hit.  MODE 1: shadow, API form (writes lit[]).  MODE 2: shadow, renderer queue form.
-template <int MODE, int K>
+// SPILL: the launch keeps a.lds_depth < sc.stack_depth entries per octet in LDS; the bottom half of an octet's LDS part
+// moves to the wave's overflow area in memory when a push might not fit, and comes back when the LDS part runs empty.
+template <int MODE, int K, bool SPILL>
 __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArgs a) {
     constexpr uint32_t SRX_RAYS_PER_BLOCK = SRX_OCTETS_PER_BLOCK * K;
     // LDS: traversal stack [depth][octets of the block] of (tmin bits << 32 | link), then one 16-B best-hit record per octet
     extern __shared__ unsigned long long s_mem[];
     unsigned long long* const s_stack = s_mem;
-    uint4* const s_best = (uint4*)(s_mem + (size_t)sc.stack_depth * SRX_OCTETS_PER_BLOCK);
+    const int D = a.lds_depth;
+    uint4* const s_best = (uint4*)(s_mem + (size_t)D * SRX_OCTETS_PER_BLOCK);
     const int sub = threadIdx.x & 7;
     const int oct = threadIdx.x >> 3;
     const int lane = threadIdx.x & 63;
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const uint32_t n_rays = a.n;
     float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {o, d.x}, {d.yz, inv.xy}, {inv.z, fused}
     float* const s_pt = (float*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening
+    uint32_t* const s_spilled = (uint32_t*)(s_pt + K * SRX_OCTETS_PER_BLOCK);   // [octets]: entries parked in memory (SPILL)
     // (LDS per wave = 64 B x stack depth + 1 792 B; 5 120 B is what 32 waves per CU can have)
 
     // ---- set-up of all K rays of the octet at once: lane `sub` prepares ray `sub`
@@ -265,6 +277,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
 
     int sp = live ? 0 : -1;
     if (sub == 0) s_stack[oct] = 0ull;   // root: node 0, distance 0, no packets (Core.h:59-61)
+    if (SPILL && sub == 0) s_spilled[oct] = 0u;
+    int spill_slot = -1;                 // wave-uniform: this wave's overflow area, claimed at its first spill
+    bool any_spilled = false;            // wave-uniform: some octet has entries in memory
     __builtin_amdgcn_wave_barrier();
 
     while (__builtin_amdgcn_ballot_w64(sp >= 0) != 0ull) {
@@ -358,9 +373,56 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                             if (sub == w) s_best[oct] = make_uint4(f2u(uu), f2u(vv), off + 256u + 64u - 12u * (uint32_t)sub, 0u);
                         } else if (best_t <= 9999.0f) {
                             sp = -1;   // any occluder nearer than 9999 => shadowed (Primitives.h:44-50)
+                            if (SPILL && any_spilled) s_spilled[oct] = 0u;
                         }
                     }
                 }
+            }
+        }
+        if (SPILL) {
+            // Room for the next trip's push (one pop, up to 8 children) is made here, where the whole wave is together:
+            // the bottom half of the LDS part goes to memory, the rest moves down. An octet whose LDS part is empty
+            // while entries are parked takes the last half back. Neither happens on the scenes measured so far (the
+            // bound is a worst case); the cost on every trip is one compare and two uniform branches.
+            const bool over = sp > D - 8;
+            const unsigned long long ob = __builtin_amdgcn_ballot_w64(over);
+            if (any_spilled || ob != 0ull) {
+                const int H = D >> 1;
+                uint32_t parked = s_spilled[oct];
+                const bool under = sp < 0 && parked > 0u;
+                if (ob != 0ull && spill_slot < 0) {
+                    int got = -1;
+                    if (lane == 0) {
+                        for (int tries = 0; tries < (1 << 16) && got < 0; tries++) {
+                            const uint32_t i = atomicAdd(&sc.spill_ctl[0], 1u) & (SRX_SPILL_SLOTS - 1u);
+                            if (atomicCAS(&sc.spill_ctl[16 + i], 0u, 1u) == 0u) got = (int)i;
+                        }
+                        if (got < 0) atomicExch(&sc.spill_ctl[1], 1u);   // the host reports it; the rays concerned end early
+                        else atomicAdd(&sc.spill_ctl[2], 1u);
+                    }
+                    spill_slot = __builtin_amdgcn_readfirstlane(got);
+                }
+                unsigned long long* const area = sc.spill_area + ((size_t)(spill_slot < 0 ? 0 : spill_slot) * SRX_OCTETS_PER_BLOCK + oct) * (size_t)sc.stack_depth;
+                if (over) {
+                    if (spill_slot < 0) {
+                        sp = -1; parked = 0u;      // no area (cannot happen with SRX_SPILL_SLOTS > resident waves): flagged above
+                    } else {
+                        for (int i = sub; i < H; i += 8)
+                            __hip_atomic_store(&area[parked + i], s_stack[i * SRX_OCTETS_PER_BLOCK + oct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int i = sub; i + H <= sp; i += 8) {
+                            const unsigned long long e = s_stack[(i + H) * SRX_OCTETS_PER_BLOCK + oct];
+                            s_stack[i * SRX_OCTETS_PER_BLOCK + oct] = e;
+                        }
+                        sp -= H; parked += (uint32_t)H;
+                    }
+                } else if (under) {
+                    for (int i = sub; i < H; i += 8)
+                        s_stack[i * SRX_OCTETS_PER_BLOCK + oct] = __hip_atomic_load(&area[parked - H + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sp = H - 1; parked -= (uint32_t)H;
+                }
+                if (sub == 0) s_spilled[oct] = parked;
+                any_spilled = __builtin_amdgcn_ballot_w64(parked > 0u) != 0ull;
+                __builtin_amdgcn_wave_barrier();
             }
         }
         if (K > 1) {
@@ -390,6 +452,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     }
 
     if (K == 1 && live) finish(ray);
+    if (SPILL && spill_slot >= 0 && lane == 0) __hip_atomic_store(&sc.spill_ctl[16 + spill_slot], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (a.counters) {
         // one atomic per wave and counter, spread over replicated slots (a single hot word serialises the chip)
         uint32_t wn = (live && sub == 0) ? n_nodes : 0u, wp = (live && sub == 0) ? n_packets : 0u;
@@ -406,33 +469,55 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     }
 }
 
-static size_t trace_lds_bytes(int stack_depth, int k) {
-    return (size_t)stack_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
-           (size_t)SRX_OCTETS_PER_BLOCK * k * (3 * sizeof(float4) + sizeof(float));
+static size_t trace_lds_bytes(int lds_depth, int k, bool spill) {
+    return (size_t)lds_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
+           (size_t)SRX_OCTETS_PER_BLOCK * k * (3 * sizeof(float4) + sizeof(float)) + (spill ? SRX_OCTETS_PER_BLOCK * sizeof(uint32_t) : 0);
 }
 
-template <int K>
+template <int K, bool SPILL>
 static void launch_k(int mode, uint32_t blocks, size_t lds, const GScene& sc, const TraceArgs& a, hipStream_t stream) {
-    if (mode == 0) hipLaunchKernelGGL((k_trace<0, K>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_trace<1, K>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
-    else hipLaunchKernelGGL((k_trace<2, K>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+    if (mode == 0) hipLaunchKernelGGL((k_trace<0, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_trace<1, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+    else hipLaunchKernelGGL((k_trace<2, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
 }
 
-extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& a, hipStream_t stream) {
-    if (a.n == 0) return hipSuccess;
-    int k = SRX_RAYS_PER_OCTET_MAX;
-    while (k > 1 && trace_lds_bytes(sc.stack_depth, k) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) k >>= 1;
+extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& args, hipStream_t stream) {
+    if (args.n == 0) return hipSuccess;
+    TraceArgs a = args;
+    // Stack entries per octet in LDS: the tree's worst case when that still lets 32 waves share a CU with 4 rays per
+    // octet (depth <= 52); a deeper tree keeps SRX_SPILL_LDS_DEPTH entries in LDS and the overflow area behind them.
+    // SRX_LDS_STACK=<n> forces n (tests: the spill path on ordinary scenes).
+    int depth = sc.stack_depth;
+    bool spill = false;
+    if (sc.spill_area && trace_lds_bytes(depth, SRX_RAYS_PER_OCTET_MAX, false) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY && depth > SRX_SPILL_LDS_DEPTH) {
+        depth = SRX_SPILL_LDS_DEPTH; spill = true;
+    }
+    if (const char* e = getenv("SRX_LDS_STACK")) {
+        const int forced_depth = atoi(e) & ~1;
+        if (sc.spill_area && forced_depth >= SRX_SPILL_MIN_LDS_DEPTH && forced_depth < sc.stack_depth) { depth = forced_depth; spill = true; }
+        else if (forced_depth >= sc.stack_depth) { depth = sc.stack_depth; spill = false; }
+    }
+    a.lds_depth = depth;
+    int k = spill ? SRX_RAYS_PER_OCTET_SPILL : SRX_RAYS_PER_OCTET_MAX;
+    while (k > 1 && trace_lds_bytes(depth, k, spill) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) k >>= 1;
     // a launch that cannot fill the chip's 8 192 wave slots (256 CUs x 32) with K rays per octet takes fewer: more waves,
     // each a shorter serial chain (the last generations of a pass are launches of a few thousand rays)
     while (k > 1 && (uint64_t)a.n < 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
     static const int forced = [] { const char* e = getenv("SRX_RAYS_PER_OCTET"); return e ? atoi(e) : 0; }();   // experiments
-    if (forced == 1 || forced == 2 || forced == 4) k = forced;
+    if (forced == 1 || forced == 2 || forced == 4 || (forced == 8 && spill)) k = forced;
     const uint32_t rays_per_block = SRX_OCTETS_PER_BLOCK * (uint32_t)k;
     uint32_t blocks = (a.n + rays_per_block - 1) / rays_per_block;
     blocks = (blocks + 7u) & ~7u;   // multiple of 8 so the XCD map covers every logical block exactly once
-    const size_t lds = trace_lds_bytes(sc.stack_depth, k);
-    if (k == 4) launch_k<4>(mode, blocks, lds, sc, a, stream);
-    else if (k == 2) launch_k<2>(mode, blocks, lds, sc, a, stream);
-    else launch_k<1>(mode, blocks, lds, sc, a, stream);
+    const size_t lds = trace_lds_bytes(depth, k, spill);
+    if (spill) {
+        if (k == 8) launch_k<8, true>(mode, blocks, lds, sc, a, stream);
+        else if (k == 4) launch_k<4, true>(mode, blocks, lds, sc, a, stream);
+        else if (k == 2) launch_k<2, true>(mode, blocks, lds, sc, a, stream);
+        else launch_k<1, true>(mode, blocks, lds, sc, a, stream);
+    } else {
+        if (k == 4) launch_k<4, false>(mode, blocks, lds, sc, a, stream);
+        else if (k == 2) launch_k<2, false>(mode, blocks, lds, sc, a, stream);
+        else launch_k<1, false>(mode, blocks, lds, sc, a, stream);
+    }
     return hipGetLastError();
 }

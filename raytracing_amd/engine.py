@@ -146,6 +146,10 @@ class RayEngine:
     def stack_bound(self):
         return self.L.srx_scene_stack_bound(self.scene)
 
+    def stack_spills(self):
+        """How often a traversal wave has moved part of its stack to the scene's overflow areas (deep trees only)."""
+        return int(self.L.srx_scene_stack_spills(self.scene))
+
     # ---- casts ---------------------------------------------------------
     def execute_ray_cast(self, position, slope, want_advanced=False):
         """`execute_ray_cast(XYZ& position, const XYZ& slope)` (Core.h:346) over a batch.

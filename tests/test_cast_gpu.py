@@ -182,6 +182,45 @@ def test_every_rays_per_octet_choice(tables):
     RE.close()
 
 
+@pytest.mark.parametrize("lds_stack", [16, 24])
+def test_stack_overflow_to_memory(tables, monkeypatch, lds_stack):
+    """Deep trees keep only the top of the traversal stack in LDS: the bottom half of an octet's part moves to an
+    overflow area in memory when a push might not fit and comes back when the LDS part runs empty. SRX_LDS_STACK forces
+    that onto an ordinary scene (16 / 24 entries in LDS against a bound of 40+): closest hits, shadow answers and the
+    traversal counters must not change, and the path must really have run (spill count > 0)."""
+    from oracle import sro
+    from raytracing_amd import engine, scenes
+    desc = scenes.atrium(32768, res=(160, 90), subdiv=2, tex_size=64)
+    PS = engine.package(desc, tables=tables)
+    S = sro.OracleScene(desc, tables=tables)
+    RE = engine.RayEngine(0)
+    RE.load_scene(PS)
+    assert RE.stack_bound() > 24
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    dirs, _ = sro.camera_rays_keyed(cam, (0, 0, w, h), 0, 7)
+    org = np.tile(np.asarray(cam["position"], np.float32), (len(dirs), 1))
+    # 600 000 rays: enough for the launcher to take the spill form's 8 rays per octet (14 400 primaries run 1 per octet)
+    o2, d2 = random_rays(600_000, seed=21, extent=float(np.abs(desc.tris["p"]).max()))
+    monkeypatch.setenv("SRX_LDS_STACK", str(lds_stack))
+    before = RE.stack_spills()
+    for o, d in ((org, dirs), (o2, d2)):
+        g, gc = RE.execute_ray_cast(o, d)
+        c, cc = S.cast_closest(o, d)
+        _assert_hits_equal(g, c)
+        assert int(gc[0]) == int(cc[0]) and int(gc[1]) == int(cc[1]) - int(cc[3])
+    sun = np.array([0.1, 0.2, 0.97], np.float32)
+    lit_g = RE.execute_lighting_cast(o2, sun)
+    lit_c = S.cast_shadow(o2, np.tile(sun, (len(o2), 1)))
+    assert np.array_equal(lit_g, lit_c)
+    spills = RE.stack_spills() - before
+    assert spills > 0, "the forced LDS depth never overflowed: the test does not exercise the path"
+    monkeypatch.delenv("SRX_LDS_STACK")
+    g, gc = RE.execute_ray_cast(o2, d2)
+    assert RE.stack_spills() - before == spills          # the default launch of this scene keeps the whole stack in LDS
+    RE.close()
+
+
 def test_malformed_package_is_refused(tables):
     """srx_scene_create checks what the kernels rely on before anything is uploaded: a child link that points back
     (a cycle would never end on the GPU), a child or packet range past the arrays, a packet whose material or triangle
