@@ -172,3 +172,41 @@ def test_malformed_files_fail_loudly(tmp_path):
     open(tmp_path / "cut.glb", "wb").write(b[:len(b) // 2])
     with pytest.raises(_lib.SrxError):
         gltf.load_gltf_file(tmp_path / "cut.glb", 4, 4)
+
+
+def test_mutated_files_are_loaded_or_refused(tmp_path):
+    """300 mutations of a good .glb (truncations, bit flips, random runs, changed JSON digits): every one either loads
+    or raises SrxError; none may take the process down. (`tools/fuzz_gltf.sh` runs thousands under ASan + UBSan.)"""
+    import struct
+    from raytracing_amd import gltf, _lib
+    good = tmp_path / "good.glb"
+    write_test_scene(str(good), seed=3, textures=True)
+    data = good.read_bytes()
+    json_len = struct.unpack_from("<I", data, 12)[0]
+    rng = np.random.default_rng(11)
+    loaded = refused = 0
+    for it in range(300):
+        v = bytearray(data)
+        kind = it % 4
+        if kind == 0:
+            v = v[: int(rng.integers(0, len(v)))]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 9))):
+                v[int(rng.integers(0, len(v)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:
+            for _ in range(4):
+                p = 20 + int(rng.integers(0, json_len))
+                if 48 <= v[p] <= 57:
+                    v[p] = 48 + int(rng.integers(0, 10))
+        else:
+            p = int(rng.integers(0, len(v)))
+            n = int(rng.integers(0, 64))
+            v[p:p + n] = rng.integers(0, 256, size=len(v[p:p + n]), dtype=np.uint8).tobytes()
+        f = tmp_path / "cur.glb"
+        f.write_bytes(bytes(v))
+        try:
+            gltf.load_gltf_file(str(f), 32, 18, 1)
+            loaded += 1
+        except _lib.SrxError:
+            refused += 1
+    assert loaded + refused == 300 and refused > 50
