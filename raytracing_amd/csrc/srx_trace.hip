@@ -29,18 +29,18 @@
 // rays costs three LDS reads.
 // Measured (bench workload, before K became a template parameter): K = 1 / 2 / 3 / 4 / 5 / 6 / 8 -> 1002 / 1007 / 1031 / 1041 / 1044 / 944 / 950 Mrays/s (the
 // shadow kernel gains 12 %, the closest-hit kernel nothing; from K = 6 the LDS footprint costs a wave per SIMD).
-// K is a template parameter: the launcher takes the largest of 4 / 2 / 1 (8 in the SPILL form) whose LDS footprint (64 B x stack depth +
+// K is a template parameter: the launcher takes the largest of 8 / 4 / 2 / 1 whose LDS footprint (64 B x LDS stack depth +
 // 128 + 416 K bytes per wave) still lets 32 waves share a CU's 160 KB, because near 8 waves per SIMD the kernel's time
 // goes 1:1 with the waves in flight. Results do not depend on K.
-#define SRX_RAYS_PER_OCTET_MAX 4
+#define SRX_RAYS_PER_OCTET_MAX 8
 #define SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY 5120u
-// Trees deeper than 52 (no room for the whole stack in LDS at 4 rays per octet and 32 waves per CU): 24 entries per
-// octet in LDS, the rest in the overflow area, and the LDS this frees goes to a pool of 8 rays per octet (5 024 B per
-// wave). On the bench scene (depth 47, stack wholly in LDS: 1404 Mrays/s on one stream) this form measured 1411 with 8
-// rays per octet and 1370 with 4: the overflow checks cost the closest-hit kernel 2 % and the shadow kernel 5 %, the
-// larger pool gives 3 % back; it is used where the plain form would have to halve the rays per octet instead.
+// SPILL form: 24 stack entries per octet in LDS, the rest in the overflow area, and the LDS this frees goes to a pool of
+// 8 rays per octet (5 024 B per wave). A tree whose worst-case stack exceeds 25 entries cannot have that pool with its
+// whole stack in LDS, one beyond 52 not even 4 rays per octet. On the bench scene (bound 47, no ray ever holds more than
+// 18 entries) the plain form with 4 rays per octet runs 1403 Mrays/s on one stream, the SPILL form with 8 runs 1424 and
+// with 4 only 1385: the overflow check costs about 1 % per trip, the larger pool returns 3 %. The launcher takes the
+// form that carries more rays per octet for the launch at hand.
 #define SRX_SPILL_LDS_DEPTH 24
-#define SRX_RAYS_PER_OCTET_SPILL 8
 
 
 // ---- cross-lane helpers inside an octet, all DPP (no LDS crossbar): quad_perm for lane^1, ^2, ^3 and
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     if (sub == 0) s_stack[oct] = 0ull;   // root: node 0, distance 0, no packets (Core.h:59-61)
     if (SPILL && sub == 0) s_spilled[oct] = 0u;
     int spill_slot = -1;                 // wave-uniform: this wave's overflow area, claimed at its first spill
-    bool any_spilled = false;            // wave-uniform: some octet has entries in memory
+    unsigned long long spilled_mask = 0ull;   // wave-uniform: lanes of the octets that have entries in memory
     __builtin_amdgcn_wave_barrier();
 
     while (__builtin_amdgcn_ballot_w64(sp >= 0) != 0ull) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                             if (sub == w) s_best[oct] = make_uint4(f2u(uu), f2u(vv), off + 256u + 64u - 12u * (uint32_t)sub, 0u);
                         } else if (best_t <= 9999.0f) {
                             sp = -1;   // any occluder nearer than 9999 => shadowed (Primitives.h:44-50)
-                            if (SPILL && any_spilled) s_spilled[oct] = 0u;
+                            if (SPILL && spilled_mask != 0ull) s_spilled[oct] = 0u;
                         }
                     }
                 }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             // bound is a worst case); the cost on every trip is one compare and two uniform branches.
             const bool over = sp > D - 8;
             const unsigned long long ob = __builtin_amdgcn_ballot_w64(over);
-            if (any_spilled || ob != 0ull) {
+            if ((ob | spilled_mask) != 0ull) {
                 const int H = D >> 1;
                 uint32_t parked = s_spilled[oct];
                 const bool under = sp < 0 && parked > 0u;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                     sp = H - 1; parked -= (uint32_t)H;
                 }
                 if (sub == 0) s_spilled[oct] = parked;
-                any_spilled = __builtin_amdgcn_ballot_w64(parked > 0u) != 0ull;
+                spilled_mask = __builtin_amdgcn_ballot_w64(parked > 0u);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -484,27 +484,34 @@ static void launch_k(int mode, uint32_t blocks, size_t lds, const GScene& sc, co
 extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& args, hipStream_t stream) {
     if (args.n == 0) return hipSuccess;
     TraceArgs a = args;
-    // Stack entries per octet in LDS: the tree's worst case when that still lets 32 waves share a CU with 4 rays per
-    // octet (depth <= 52); a deeper tree keeps SRX_SPILL_LDS_DEPTH entries in LDS and the overflow area behind them.
-    // SRX_LDS_STACK=<n> forces n (tests: the spill path on ordinary scenes).
+    // Rays per octet for a form of the kernel: the most whose LDS footprint lets 32 waves share a CU, fewer for a launch
+    // that cannot fill the chip's 8 192 wave slots (256 CUs x 32) with that many (more waves, each a shorter serial
+    // chain: the last generations of a pass are launches of a few thousand rays).
+    auto rays_per_octet = [&](int lds_depth, bool spill_form) {
+        int k = SRX_RAYS_PER_OCTET_MAX;
+        while (k > 1 && trace_lds_bytes(lds_depth, k, spill_form) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) k >>= 1;
+        while (k > 1 && (uint64_t)a.n < 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
+        return k;
+    };
+    // Plain form (the tree's whole worst-case stack in LDS) or SPILL form (SRX_SPILL_LDS_DEPTH entries in LDS, the
+    // overflow area behind them): whichever carries more rays per octet, and the SPILL form when the plain one cannot
+    // keep 32 waves per CU at all. SRX_LDS_STACK=<n> forces n entries (tests: the spill path on ordinary scenes).
     int depth = sc.stack_depth;
     bool spill = false;
-    if (sc.spill_area && trace_lds_bytes(depth, SRX_RAYS_PER_OCTET_MAX, false) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY && depth > SRX_SPILL_LDS_DEPTH) {
-        depth = SRX_SPILL_LDS_DEPTH; spill = true;
+    int k = rays_per_octet(depth, false);
+    if (sc.spill_area && sc.stack_depth > SRX_SPILL_LDS_DEPTH) {
+        const int ks = rays_per_octet(SRX_SPILL_LDS_DEPTH, true);
+        if (ks > k || trace_lds_bytes(depth, k, false) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) { depth = SRX_SPILL_LDS_DEPTH; spill = true; k = ks; }
     }
     if (const char* e = getenv("SRX_LDS_STACK")) {
         const int forced_depth = atoi(e) & ~1;
         if (sc.spill_area && forced_depth >= SRX_SPILL_MIN_LDS_DEPTH && forced_depth < sc.stack_depth) { depth = forced_depth; spill = true; }
         else if (forced_depth >= sc.stack_depth) { depth = sc.stack_depth; spill = false; }
+        k = rays_per_octet(depth, spill);
     }
     a.lds_depth = depth;
-    int k = spill ? SRX_RAYS_PER_OCTET_SPILL : SRX_RAYS_PER_OCTET_MAX;
-    while (k > 1 && trace_lds_bytes(depth, k, spill) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) k >>= 1;
-    // a launch that cannot fill the chip's 8 192 wave slots (256 CUs x 32) with K rays per octet takes fewer: more waves,
-    // each a shorter serial chain (the last generations of a pass are launches of a few thousand rays)
-    while (k > 1 && (uint64_t)a.n < 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
     static const int forced = [] { const char* e = getenv("SRX_RAYS_PER_OCTET"); return e ? atoi(e) : 0; }();   // experiments
-    if (forced == 1 || forced == 2 || forced == 4 || (forced == 8 && spill)) k = forced;
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) k = forced;
     const uint32_t rays_per_block = SRX_OCTETS_PER_BLOCK * (uint32_t)k;
     uint32_t blocks = (a.n + rays_per_block - 1) / rays_per_block;
     blocks = (blocks + 7u) & ~7u;   // multiple of 8 so the XCD map covers every logical block exactly once
@@ -515,7 +522,8 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
         else if (k == 2) launch_k<2, true>(mode, blocks, lds, sc, a, stream);
         else launch_k<1, true>(mode, blocks, lds, sc, a, stream);
     } else {
-        if (k == 4) launch_k<4, false>(mode, blocks, lds, sc, a, stream);
+        if (k == 8) launch_k<8, false>(mode, blocks, lds, sc, a, stream);
+        else if (k == 4) launch_k<4, false>(mode, blocks, lds, sc, a, stream);
         else if (k == 2) launch_k<2, false>(mode, blocks, lds, sc, a, stream);
         else launch_k<1, false>(mode, blocks, lds, sc, a, stream);
     }

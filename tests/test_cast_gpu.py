@@ -215,9 +215,16 @@ def test_stack_overflow_to_memory(tables, monkeypatch, lds_stack):
     assert np.array_equal(lit_g, lit_c)
     spills = RE.stack_spills() - before
     assert spills > 0, "the forced LDS depth never overflowed: the test does not exercise the path"
-    monkeypatch.delenv("SRX_LDS_STACK")
-    g, gc = RE.execute_ray_cast(o2, d2)
-    assert RE.stack_spills() - before == spills          # the default launch of this scene keeps the whole stack in LDS
+    # the launcher's own choice (8 rays per octet over 24 LDS entries for a launch of this size) gives the same again,
+    # and so does the whole worst-case stack in LDS
+    for forced in (None, "999"):
+        if forced is None:
+            monkeypatch.delenv("SRX_LDS_STACK")
+        else:
+            monkeypatch.setenv("SRX_LDS_STACK", forced)
+        g, gc = RE.execute_ray_cast(o2, d2)
+        _assert_hits_equal(g, c)
+        assert int(gc[0]) == int(cc[0]) and int(gc[1]) == int(cc[1]) - int(cc[3])
     RE.close()
 
 
