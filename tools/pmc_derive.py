@@ -8,11 +8,11 @@ tot = defaultdict(float); disp = defaultdict(int)
 for line in open(sys.argv[1]):
     m = re.match(r"(.*?)\s+(\S+)\s+total\s+(\S+)\s+per_dispatch\s+\S+\s+dispatches\s+(\d+)", line)
     if m and not line.startswith("#"):
-        k = re.sub(r"<(\d), \d>", r"<\1>", m.group(1).strip().replace("void ", ""))     # fold the K variants of a mode
+        k = re.sub(r"<(\d), \d(?:, \w+)?>", r"<\1>", m.group(1).strip().replace("void ", ""))     # fold the K variants of a mode
         tot[(k, m.group(2))] += float(m.group(3)); disp[(k, m.group(2))] += int(m.group(4))
 ms = defaultdict(float)
 for r in csv.DictReader(open(sys.argv[2])):
-    k = re.sub(r"<(\d), \d>", r"<\1>", r["Name"].split("(")[0].replace("void ", ""))
+    k = re.sub(r"<(\d), \d(?:, \w+)?>", r"<\1>", r["Name"].split("(")[0].replace("void ", ""))
     ms[k] += float(r["TotalDurationNs"]) / 1e6 / int(sys.argv[3])
 out = {}
 for k in ("k_trace<0>", "k_trace<2>", "k_shade"):
