@@ -40,7 +40,13 @@
 // 18 entries) the plain form with 4 rays per octet runs 1403 Mrays/s on one stream, the SPILL form with 8 runs 1424 and
 // with 4 only 1385: the overflow check costs about 1 % per trip, the larger pool returns 3 %. The launcher takes the
 // form that carries more rays per octet for the launch at hand.
+// Where it pays is measured, not derived: +2.3 % on the atrium and +1 % on the interior (bound 47), +8 % on the 10
+// M-triangle atrium (bound 62, where the plain form is down to 2 rays per octet), but -4 % on the closed diffuse box
+// (bound 32: every ray is long, the pool has little to even out and the check is pure cost), and launches under 4 x
+// 8 192 waves of 64 rays lose more to the longer waves' tail than they gain. Hence: trees with a bound of at least 40,
+// launches of at least 2.1 M rays (SRX_K8_ROUNDS, swept 1-16 on both scenes).
 #define SRX_SPILL_LDS_DEPTH 24
+#define SRX_SPILL_MIN_BOUND 40
 
 
 // ---- cross-lane helpers inside an octet, all DPP (no LDS crossbar): quad_perm for lane^1, ^2, ^3 and
@@ -490,16 +496,17 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
     auto rays_per_octet = [&](int lds_depth, bool spill_form) {
         int k = SRX_RAYS_PER_OCTET_MAX;
         while (k > 1 && trace_lds_bytes(lds_depth, k, spill_form) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) k >>= 1;
-        while (k > 1 && (uint64_t)a.n < 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
+        static const uint64_t rounds8 = [] { const char* e = getenv("SRX_K8_ROUNDS"); return (uint64_t)(e ? atoi(e) : 4); }();
+        while (k > 1 && (uint64_t)a.n < (k == 8 ? rounds8 : 1ull) * 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
         return k;
     };
     // Plain form (the tree's whole worst-case stack in LDS) or SPILL form (SRX_SPILL_LDS_DEPTH entries in LDS, the
-    // overflow area behind them): whichever carries more rays per octet, and the SPILL form when the plain one cannot
-    // keep 32 waves per CU at all. SRX_LDS_STACK=<n> forces n entries (tests: the spill path on ordinary scenes).
+    // overflow area behind them): for trees with a bound of at least SRX_SPILL_MIN_BOUND whichever carries more rays per
+    // octet, and the SPILL form when the plain one cannot keep 32 waves per CU at all. SRX_LDS_STACK=<n> forces n entries (tests: the spill path on ordinary scenes).
     int depth = sc.stack_depth;
     bool spill = false;
     int k = rays_per_octet(depth, false);
-    if (sc.spill_area && sc.stack_depth > SRX_SPILL_LDS_DEPTH) {
+    if (sc.spill_area && sc.stack_depth >= SRX_SPILL_MIN_BOUND) {
         const int ks = rays_per_octet(SRX_SPILL_LDS_DEPTH, true);
         if (ks > k || trace_lds_bytes(depth, k, false) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) { depth = SRX_SPILL_LDS_DEPTH; spill = true; k = ks; }
     }
