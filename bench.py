@@ -274,6 +274,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.tris, args.res, args.scene) if world == 1 else None,
                 "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, bytes per launch)",
+                "note": ("frac can exceed 1: the algorithmic bytes (reference record sizes x tests the kernel counts) are served mostly by "
+                         "L1 / L2 / Infinity Cache, `traffic` is what reached the memory side; the kernel is bound by the latency of its "
+                         "dependent gathers, not by HBM bandwidth (DESIGN.md section 6)"),
                 "concurrency": ("shadow kernels run on a second stream beside this kernel: avg_launch_ms includes the time they share "
                                 "the chip (SRX_SHADOW_STREAM=0 times it alone: profiles/r01_kernel_stats_single_stream.csv)")
                                if os.environ.get("SRX_SHADOW_STREAM", "1") != "0" else "one stream",
