@@ -145,6 +145,32 @@ private:
     uint64_t capacity_;
 };
 
+// The frame a render loop accumulates into: SceneManager::raw_output / aux_output (SceneManager.h:288-289, 370-380) as
+// device float4 framebuffers {running mean r, g, b, sample count}; no HIP headers needed on the host side.
+class FrameBuffers {
+public:
+    int res_x, res_y;
+    float* raw_output = nullptr;     // device pointers
+    float* aux_output = nullptr;
+    FrameBuffers(int rx, int ry) : res_x(rx), res_y(ry) {
+        check(srx_buffer_create(bytes(), (void**)&raw_output), "srx_buffer_create");
+        check(srx_buffer_create(bytes(), (void**)&aux_output), "srx_buffer_create");
+    }
+    ~FrameBuffers() { srx_buffer_destroy(raw_output); srx_buffer_destroy(aux_output); }
+    FrameBuffers(const FrameBuffers&) = delete;
+    FrameBuffers& operator=(const FrameBuffers&) = delete;
+    uint64_t bytes() const { return (uint64_t)res_x * (uint64_t)res_y * 16u; }
+    void reset() {                                               // SceneManager::reset_blocks, SceneManager.h:478-487
+        check(srx_buffer_clear(raw_output, bytes()), "srx_buffer_clear");
+        check(srx_buffer_clear(aux_output, bytes()), "srx_buffer_clear");
+    }
+    std::vector<float> read(bool aux = false) const {            // res_x * res_y * {r, g, b, samples}
+        std::vector<float> host((size_t)res_x * res_y * 4);
+        check(srx_buffer_read(aux ? aux_output : raw_output, bytes(), host.data()), "srx_buffer_read");
+        return host;
+    }
+};
+
 // FileManager (FileLoading.h): scene in, raw frame out
 namespace FileManager {
 struct GltfScene {                                               // what parseGLTFData leaves in Scene, flattened (FileLoading.h:438-782)

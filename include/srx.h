@@ -234,6 +234,16 @@ int srx_process_rays(srx_renderer* r, const float* org3, const float* dir3, cons
 int srx_camera_rays(const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h, uint32_t pass_index,
                     uint64_t seed, float* dir3, uint64_t* keys);
 
+/* ---- device buffers for a host without a HIP toolchain. The reference keeps its framebuffers on the host
+ * (SceneManager::raw_output / aux_output, SceneManager.h:288-289, filled at :370-380); here they live on the device as
+ * res_x * res_y float4 {running mean r, g, b, sample count}. srx_buffer_create returns zeroed device memory (a
+ * framebuffer is res_x * res_y * 16 bytes, a canvas for srx_post_process res_x * res_y * 4), srx_buffer_read copies it
+ * to the host, srx_buffer_clear zeroes it again (`SceneManager::reset_blocks`, SceneManager.h:478-487). */
+int srx_buffer_create(uint64_t bytes, void** d_out);
+void srx_buffer_destroy(void* d_buf);
+int srx_buffer_read(const void* d_buf, uint64_t bytes, void* host_out);
+int srx_buffer_clear(void* d_buf, uint64_t bytes);
+
 /* ---- output stage ---------------------------------------------------------------------------
  * srx_post_process replaces the canvas conversion of SceneManager::refresh_canvas (SceneManager.h:1064-1072):
  * ImageHandler::post_process_pixel (ImageProcessing.h:137-151: luminance-preserving gamma 1, view transform,

@@ -153,6 +153,29 @@ extern "C" int srx_post_process(const float* d_accum4, int32_t res_x, int32_t re
     return 0;
 }
 
+// ---- device buffers for hosts without a HIP toolchain (the reference keeps its framebuffers on the host:
+// SceneManager::raw_output / aux_output, SceneManager.h:288-289, 370-380)
+extern "C" int srx_buffer_create(uint64_t bytes, void** d_out) {
+    if (!d_out || bytes == 0) SRX_FAIL("srx_buffer_create: null argument or zero size");
+    void* p = nullptr;
+    SRX_HIP(hipMalloc(&p, bytes));
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) { (void)hipFree(p); SRX_FAIL(std::string("srx_buffer_create: ") + hipGetErrorString(e)); }
+    *d_out = p;
+    return 0;
+}
+extern "C" void srx_buffer_destroy(void* d_buf) { if (d_buf) (void)hipFree(d_buf); }
+extern "C" int srx_buffer_read(const void* d_buf, uint64_t bytes, void* host_out) {
+    if (!d_buf || !host_out) SRX_FAIL("srx_buffer_read: null argument");
+    SRX_HIP(hipMemcpy(host_out, d_buf, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int srx_buffer_clear(void* d_buf, uint64_t bytes) {
+    if (!d_buf) SRX_FAIL("srx_buffer_clear: null argument");
+    SRX_HIP(hipMemset(d_buf, 0, bytes));
+    return 0;
+}
+
 extern "C" int srx_write_raw(const char* path, const float* d_accum4, int32_t res_x, int32_t res_y) {
     if (!path || !d_accum4) SRX_FAIL("srx_write_raw: null argument");
     if (res_x <= 0 || res_y <= 0) SRX_FAIL("srx_write_raw: bad resolution");
