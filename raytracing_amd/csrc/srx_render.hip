@@ -9,18 +9,21 @@
 // batch is sized so that its worst-case fan-out (bounce_count[g] children per ray, Core.h:428) fits in
 // the free slots, so nothing is ever dropped and small capacities only mean more, smaller launches.
 // Per batch: trace kernel -> shade kernel (appends children + shadow rays, one atomic per wave) ->
-// 8-byte count readback -> shadow kernel (adds lit direct-light contributions to the sample buffer).
+// count readback -> shadow kernel (adds lit direct-light contributions to the sample buffer).
 #include "srx_host.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
+#define SRX_COUNT_PAD 512     // dwords between the two queue counters (2 KB: measured, shade kernel 41.2 -> 40.2 ms per 4 passes)
 namespace {
 
 enum { CTR_NODES = 0, CTR_PACKETS = 1, CTR_SNODES = 2, CTR_SPACKETS = 3, CTR_HITS = 4, CTR_TEXELS = 5, CTR_PDF = 6,
        CTR_CHILDREN = 7, CTR_COUNT = 8, CTR_SLOTS = 256 };
 
-struct DeviceCounts { uint32_t out_count, shadow_count; };
+// The two queue counters take a returning atomic per block / flush of the shade kernel (~0.9 M per pass): each on a
+// memory channel of its own (the counters of the three sets are 4 KB apart as well).
+struct DeviceCounts { uint32_t out_count; uint32_t pad0[SRX_COUNT_PAD - 1]; uint32_t shadow_count; uint32_t pad1[SRX_COUNT_PAD - 1]; };
 
 }  // namespace
 

@@ -165,13 +165,16 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #ifndef SRX_STAGE
 #define SRX_STAGE 192
 #endif
-__global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
+#ifndef SRX_SHADE_WAVES
+#define SRX_SHADE_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * SRX_SHADE_WAVES) void k_shade(GScene sc, ShadeArgs a) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool live = idx < a.n;
-    __shared__ GRay s_stage[4][SRX_STAGE];          // per-wave staging of surviving children (36 KB per block: 4 blocks = 16 waves per CU, what 116 VGPRs allow)
-    __shared__ uint32_t s_wave_count[4];
+    __shared__ GRay s_stage[SRX_SHADE_WAVES][SRX_STAGE];          // per-wave staging of surviving children (36 KB per block: 4 blocks = 16 waves per CU, what 116 VGPRs allow)
+    __shared__ uint32_t s_wave_count[SRX_SHADE_WAVES];
     __shared__ uint32_t s_base[2];
     GRay* const stage = s_stage[threadIdx.x >> 6];
     uint32_t staged = 0;                      // wave-uniform
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
     __syncthreads();
     uint32_t hit_rank = (uint32_t)__popcll(hit_bal & lt_mask), block_hits = 0;
 #pragma unroll
-    for (int wv = 0; wv < 4; wv++) {
+    for (int wv = 0; wv < SRX_SHADE_WAVES; wv++) {
         const uint32_t c = s_wave_count[wv];
         if (wv < wave) hit_rank += c;
         block_hits += c;
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256) void k_shade(GScene sc, ShadeArgs a) {
     {
         uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int wv = 0; wv < 4; wv++) {
+        for (int wv = 0; wv < SRX_SHADE_WAVES; wv++) {
             const uint32_t c = s_wave_count[wv];
             if (wv < wave) before += c;
             total += c;
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(256) void k_accumulate(int res_x, int x0, int w, GR
 // ---------------------------------------------------------------- launchers
 extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_shade, dim3((a.n + 255) / 256), dim3(256), 0, stream, sc, a);
+    hipLaunchKernelGGL(k_shade, dim3((a.n + 64 * SRX_SHADE_WAVES - 1) / (64 * SRX_SHADE_WAVES)), dim3(64 * SRX_SHADE_WAVES), 0, stream, sc, a);
     return hipGetLastError();
 }
 extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, uint32_t pass_index,
