@@ -294,6 +294,10 @@ def main():
                 "avg_launch_ms": trace_ms / launches,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
                 "bytes_per_ray": alg_bytes / max(1.0, rays),
+                # the same with the bytes a test actually uses of a record (264 of the 288-B node, 324 of the
+                # 448-B packet), and what the kernel's own layout fetches per test (2 x 128-B node lines, 3 packet lines)
+                "useful_bytes_per_ray": (264 * agg["nodes"] + 324 * agg["packets"]) / max(1.0, rays) + RAY_B + HIT_B,
+                "fetched_bytes_per_ray": (256 * agg["nodes"] + 384 * agg["packets"]) / max(1.0, rays) + 24 + 20,
                 "node_tests_per_ray": agg["nodes"] / max(1.0, rays),
                 "packet_tests_per_ray": agg["packets"] / max(1.0, rays),
                 "kernel_ms": {"trace": trace_ms, "shadow": shadow_ms, "shade": shade_ms, "wall": dt * 1e3},
