@@ -197,6 +197,15 @@ def trig(x):
     return s, c, t
 
 
+def avx_ops(fields):
+    """fields[m, 10, 8] (a.xyz, b.xyz, c.xyz, s per lane) -> [m, 5, 8]: cross(a, b).xyz, dot(a, b), s * dot(a, c)
+    with the FMA nesting of VecLib.cpp:282-325 (what the packet test is made of)."""
+    f = np.ascontiguousarray(fields, np.float32).reshape(-1, 10, 8)
+    out = np.zeros((len(f), 5, 8), np.float32)
+    lib().sro_avx_ops(_p(f), C.c_uint32(len(f)), _p(out))
+    return out
+
+
 def poly_acos(x):
     x = np.ascontiguousarray(x, np.float32)
     o = np.zeros_like(x)

@@ -462,6 +462,18 @@ uint64_t sro_primary_key(uint64_t seed, uint64_t sample_index) { return KeyedGen
 void sro_trig(const float* x, uint32_t n, float* s, float* c, float* t) {
     for (uint32_t i = 0; i < n; i++) { s[i] = full_sin(x[i]); c[i] = full_cos(x[i]); t[i] = vtan(x[i]); }
 }
+// m records of 10 fields x 8 lanes (a.xyz, b.xyz, c.xyz, s) -> m records of 5 fields x 8 lanes (cross(a,b).xyz, dot(a,b), dot_mul(a,c,s))
+void sro_avx_ops(const float* in80, uint32_t m, float* out40) {
+    for (uint32_t i = 0; i < m; i++) {
+        const float* p = in80 + (size_t)i * 80;
+        float* o = out40 + (size_t)i * 40;
+        for (int l = 0; l < 8; l++) {
+            cross_avx_lane(p[l], p[8 + l], p[16 + l], p[24 + l], p[32 + l], p[40 + l], o[l], o[8 + l], o[16 + l]);
+            o[24 + l] = dot_avx_lane(p[l], p[8 + l], p[16 + l], p[24 + l], p[32 + l], p[40 + l]);
+            o[32 + l] = dot_mul_avx_lane(p[l], p[8 + l], p[16 + l], p[48 + l], p[56 + l], p[64 + l], p[72 + l]);
+        }
+    }
+}
 void sro_poly_acos(const float* x, uint32_t n, float* out) {
     for (uint32_t i = 0; i < n; i++) out[i] = MaterialSample::poly_acos(x[i]);
 }

@@ -5,10 +5,15 @@
 // the product (raytracing_amd/); only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may use it, as the checker.
 //
-// PARITY UNPINNED: the reference has no tests or golden vectors for this path
-// and its Core.h stack needs MSVC-only library constructs, so it is not built
-// here. Every function cites the reference file:line it follows
-// (paths relative to /root/reference/spatialPartitioning/).
+// PARITY UNPINNED upstream: the reference has no tests or golden vectors for
+// this path and its Core.h stack needs MSVC-only library constructs, so it is
+// not built here. What IS pinned to the reference's own object
+// code, bit for bit (tests/test_oracle_cpu.py): the XYZ / Quat vector math
+// (XYZ.cpp -> oracle/_ref/libref_xyz.so), the polynomial trig of this file and
+// the per-lane cross / dot helpers of the packet test in sro_trace.h (VecLib.cpp
+// + commons.cpp -> oracle/_ref/ref_veclib_probe). Every function cites the
+// reference file:line it follows (paths relative to
+// /root/reference/spatialPartitioning/).
 //
 // Build with -ffp-contract=off: fused operations appear only where the
 // reference writes an FMA intrinsic (std::fmaf below).

@@ -63,25 +63,34 @@ static inline void node_intersection(const BVH_AVX& n, const XYZ& fused, const X
     }
 }
 
+// One lane of the reference's AVX helpers (VecLib.cpp:282-325); tests/test_oracle_cpu.py pins them bit for bit against
+// the reference's own object code (oracle/_ref/ref_veclib_probe).
+static inline void cross_avx_lane(float ax, float ay, float az, float bx, float by, float bz, float& x, float& y, float& z) {
+    const float c1 = az * by, c2 = ax * bz, c3 = ay * bx;            // :283-285
+    x = std::fmaf(ay, bz, -c1); y = std::fmaf(az, bx, -c2); z = std::fmaf(ax, by, -c3);   // fmsub :286-288
+}
+static inline float dot_avx_lane(float ax, float ay, float az, float bx, float by, float bz) {   // :290-303
+    return std::fmaf(az, bz, std::fmaf(ay, by, ax * bx));
+}
+static inline float dot_mul_avx_lane(float ax, float ay, float az, float bx, float by, float bz, float s) {   // :309-325
+    return s * std::fmaf(az, bz, std::fmaf(ay, by, ax * bx));
+}
+
 // Primitives.h:159-202 with VecLib.cpp:282-325
 static inline void packet_intersection(const PTri_AVX& T, const XYZ& o, const XYZ& d, float t[8], float u[8], float v[8]) {
     for (int l = 0; l < 8; l++) {
         const float e1x = T.p1p2X[l], e1y = T.p1p2Y[l], e1z = T.p1p2Z[l];
         const float e2x = T.p1p3X[l], e2y = T.p1p3Y[l], e2z = T.p1p3Z[l];
-        // pvec = cross_avx(slope, p1p3)
-        float c1 = d.Z * e2y, c2 = d.X * e2z, c3 = d.Y * e2x;
-        float px = std::fmaf(d.Y, e2z, -c1), py = std::fmaf(d.Z, e2x, -c2), pz = std::fmaf(d.X, e2y, -c3);
-        // det = dot_avx(p1p2, pvec)
-        float det = std::fmaf(e1z, pz, std::fmaf(e1y, py, e1x * px));
-        float invDet = 1.0f / det;
-        float tx = o.X - T.p1X[l], ty = o.Y - T.p1Y[l], tz = o.Z - T.p1Z[l];
-        // qvec = cross_avx(tvec, p1p2)
-        float q1 = tz * e1y, q2 = tx * e1z, q3 = ty * e1x;
-        float qx = std::fmaf(ty, e1z, -q1), qy = std::fmaf(tz, e1x, -q2), qz = std::fmaf(tx, e1y, -q3);
-        float uu = invDet * std::fmaf(tz, pz, std::fmaf(ty, py, tx * px));
-        float vv = invDet * std::fmaf(d.Z, qz, std::fmaf(d.Y, qy, d.X * qx));
-        float tt = invDet * std::fmaf(e2z, qz, std::fmaf(e2y, qy, e2x * qx));
-        bool pass = (uu >= 0.0f) && (vv >= 0.0f) && ((uu + vv) <= 1.0f);
+        float px, py, pz, qx, qy, qz;
+        cross_avx_lane(d.X, d.Y, d.Z, e2x, e2y, e2z, px, py, pz);            // pvec = cross_avx(slope, p1p3)
+        const float det = dot_avx_lane(e1x, e1y, e1z, px, py, pz);           // det = dot_avx(p1p2, pvec)
+        const float invDet = 1.0f / det;
+        const float tx = o.X - T.p1X[l], ty = o.Y - T.p1Y[l], tz = o.Z - T.p1Z[l];
+        cross_avx_lane(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);               // qvec = cross_avx(tvec, p1p2)
+        const float uu = dot_mul_avx_lane(tx, ty, tz, px, py, pz, invDet);
+        const float vv = dot_mul_avx_lane(d.X, d.Y, d.Z, qx, qy, qz, invDet);
+        const float tt = dot_mul_avx_lane(e2x, e2y, e2z, qx, qy, qz, invDet);
+        const bool pass = (uu >= 0.0f) && (vv >= 0.0f) && ((uu + vv) <= 1.0f);
         t[l] = pass ? tt : 0.0f;
         u[l] = uu;
         v[l] = vv;
