@@ -90,6 +90,10 @@ class OracleScene:
         elif build_tables:
             self.L.sro_scene_build_tables(self.h)
 
+    def set_leaf_filter(self, enabled):
+        """Mirror of the product's SRX_LEAF_FILTER switch: off = count no packet test as saved."""
+        self.L.sro_scene_set_leaf_filter(self.h, C.c_int32(int(bool(enabled))))
+
     def set_params(self, max_generations, monte_carlo_max, monte_carlo_modifier):
         self.L.sro_scene_set_params(self.h, C.c_int32(max_generations), C.c_int32(monte_carlo_max), C.c_float(monte_carlo_modifier))
 
@@ -121,7 +125,7 @@ class OracleScene:
         n = len(org)
         out = np.zeros(n, HIT_DTYPE)
         adv = np.zeros((n, 3), np.float32) if want_advanced else None
-        ctr = np.zeros(4, np.uint64)
+        ctr = np.zeros(7, np.uint64)
         self._chk(self.L.sro_cast_closest(self.h, _p(org), _p(dirs), C.c_uint32(n), _p(out), _p(adv), _p(ctr)))
         return (out, ctr, adv) if want_advanced else (out, ctr)
 

@@ -93,6 +93,9 @@ int sro_scene_set_packaged(void* hv, const void* nodes, uint32_t n_nodes, const 
     return 0;
 }
 
+// mirrors the product's SRX_LEAF_FILTER=0: with the filter off nothing is counted as saved
+void sro_scene_set_leaf_filter(void* hv, int32_t enabled) { ((Handle*)hv)->scene.geo.filter_enabled = enabled != 0; }
+
 uint32_t sro_scene_counts(void* hv, uint32_t* n_nodes, uint32_t* n_packets, uint32_t* n_tris) {
     Handle* h = (Handle*)hv;
     *n_nodes = (uint32_t)h->scene.geo.avx_bvh.size();
@@ -170,7 +173,9 @@ const float* sro_scene_arccos(void* hv) { return ((Handle*)hv)->scene.tables.arc
 const float* sro_scene_pdf(void* hv) { return ((Handle*)hv)->scene.tables.pdf_lookup.data(); }
 
 // ---- casts ---------------------------------------------------------------
-// counters4 (optional) = {node visits, packet tests, max stack depth, packet tests the product's leaf filter saves}.
+// counters6 (optional) = {node visits, packet tests, max stack depth, packet tests the product's leaf filter saves,
+// closest-hit updates taken inside a leaf that filter skips (any > 0 = the filter changes a result), lanes that pass the
+// triangle test with t > 0 in such a leaf, packet tests in leaves the box test would skip but the cone guard keeps}.
 int sro_cast_closest(void* hv, const float* org3, const float* dir3, uint32_t n, sro_hit* out, float* advanced_org3,
                      uint64_t* counters4) {
     Handle* h = (Handle*)hv;
@@ -186,7 +191,10 @@ int sro_cast_closest(void* hv, const float* org3, const float* dir3, uint32_t n,
             if (advanced_org3) { advanced_org3[3 * i] = o.X; advanced_org3[3 * i + 1] = o.Y; advanced_org3[3 * i + 2] = o.Z; }
         }
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
-    if (counters4) { counters4[0] = c.nodes; counters4[1] = c.packets; counters4[2] = (uint64_t)c.max_stack; counters4[3] = c.packets_unhittable; }
+    if (counters4) {
+        counters4[0] = c.nodes; counters4[1] = c.packets; counters4[2] = (uint64_t)c.max_stack; counters4[3] = c.packets_unhittable;
+        counters4[4] = c.unhittable_accepts; counters4[5] = c.unhittable_passes; counters4[6] = c.packets_guarded;
+    }
     return 0;
 }
 

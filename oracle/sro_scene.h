@@ -303,7 +303,57 @@ struct PackagedGeometry {
     // except that a leaf box containing the origin on every axis has its planes at 0 replaced by the tight bound of
     // the leaf's triangles (from the packets, clamped into the reference box)
     std::vector<float> filter_boxes;
+    std::vector<uint32_t> filter_cones;    // [node][child]: the leaf's normal-cone word (see leaf_cone_word), 0 = no guard needed
     float filter_pad = 0.0f;
+    bool filter_enabled = true;            // mirrors SRX_LEAF_FILTER=0 of the product
+    static constexpr float FILTER_PAD_REL = 5.0e-4f;   // pad = this x the largest |coordinate difference| between the ray's origin and the leaf's box ...
+    static constexpr float FILTER_PAD_ABS = 4.0e-6f;   // ... + this x (scene size + largest |origin coordinate|): rounding of the slab test itself
+    static constexpr uint32_t CONE_NEVER = 0xFF000000u;
+
+    // NOT part of the reference. The guard word of a leaf: when a ray is closer than asin(kappa / sin(gamma)) to the
+    // plane of a triangle (gamma = angle between its edges), the reference's fp32 Moller-Trumbore (Primitives.h:159-202)
+    // divides by a det that is mostly rounding error and may accept a "hit" far outside the triangle, so a leaf may
+    // only be skipped for rays that keep that distance from the planes of ALL its triangles. Stored as a cone around
+    // the mean normal: bytes 0-2 = axis a (int8, largest component +-127), byte 3 = h: the leaf may be skipped iff
+    // |a . dq| >= 127 h with dq = round(127 d / |d|); h = 255 never. Same arithmetic, in double, as srx_scene.hip.
+    uint32_t leaf_cone_word(uint32_t first, uint32_t count) const {
+        const double kappa = 1.0 / 80.0;
+        struct V { double x, y, z; };
+        std::vector<V> nh; std::vector<double> tau;
+        V sum = {0, 0, 0};
+        for (uint32_t p = first; p < first + count; p++) {
+            const PTri_AVX& P = avx_tri_data[p];
+            for (int k = 0; k < 8 && k < (int)P.size; k++) {
+                const double ax = P.p1p2X[k], ay = P.p1p2Y[k], az = P.p1p2Z[k], bx = P.p1p3X[k], by = P.p1p3Y[k], bz = P.p1p3Z[k];
+                const double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+                const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+                const double ll = std::sqrt(ax * ax + ay * ay + az * az) * std::sqrt(bx * bx + by * by + bz * bz);
+                if (!(ll >= 1e-16) || !(ll <= 1e16) || !(nn > 0.0)) return CONE_NEVER;
+                const double t = kappa / (nn / ll);
+                if (!(t < 1.0)) return CONE_NEVER;
+                V n = {nx / nn, ny / nn, nz / nn};
+                if (!nh.empty() && n.x * nh[0].x + n.y * nh[0].y + n.z * nh[0].z < 0.0) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
+                nh.push_back(n); tau.push_back(t);
+                sum.x += n.x; sum.y += n.y; sum.z += n.z;
+            }
+        }
+        if (nh.empty()) return 0u;
+        const double m = std::max(std::fabs(sum.x), std::max(std::fabs(sum.y), std::fabs(sum.z)));
+        if (!(m > 1e-6)) return CONE_NEVER;
+        const double a[3] = {std::floor(sum.x / m * 127.0 + 0.5), std::floor(sum.y / m * 127.0 + 0.5), std::floor(sum.z / m * 127.0 + 0.5)};
+        const double A = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        double thr = 0.0;
+        for (size_t k = 0; k < nh.size(); k++) {
+            const double c = std::fabs(nh[k].x * a[0] + nh[k].y * a[1] + nh[k].z * a[2]) / A;
+            if (!(tau[k] < c)) return CONE_NEVER;
+            const double s = std::sqrt(std::max(0.0, 1.0 - c * c));
+            thr = std::max(thr, tau[k] * c + std::sqrt(1.0 - tau[k] * tau[k]) * s);
+        }
+        const double h = std::ceil(thr * A + (std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2])) / 254.0 + 0.01);
+        if (!(h <= 254.0)) return CONE_NEVER;
+        return ((uint32_t)(int)a[0] & 255u) | (((uint32_t)(int)a[1] & 255u) << 8) | (((uint32_t)(int)a[2] & 255u) << 16) | ((uint32_t)(int)h << 24);
+    }
+
     void build_filter_boxes() {
         auto bounds = [&](uint32_t first, uint32_t count, float* mn, float* mx) {
             for (int ax = 0; ax < 3; ax++) { mn[ax] = 3.0e38f; mx[ax] = -3.0e38f; }
@@ -326,8 +376,9 @@ struct PackagedGeometry {
             for (int ax = 0; ax < 3; ax++)
                 if (mx[ax] >= mn[ax]) scale = std::max(scale, std::max(mx[ax] - mn[ax], std::max(std::fabs(mn[ax]), std::fabs(mx[ax]))));
         }
-        filter_pad = 1e-4f * scale;
+        filter_pad = FILTER_PAD_ABS * scale;
         filter_boxes.assign(avx_bvh.size() * 48, 0.0f);
+        filter_cones.assign(avx_bvh.size() * 8, 0u);
         for (size_t i = 0; i < avx_bvh.size(); i++)
             for (int k = 0; k < 8; k++)
                 if (avx_bvh[i].leaf_size[k] > 0) {
@@ -344,6 +395,7 @@ struct PackagedGeometry {
                         else if (rmin[ax] == 0.0f) f[ax] = std::min(std::max(mn[ax], 0.0f), rmax[ax]);
                         else if (rmax[ax] == 0.0f) f[3 + ax] = std::max(std::min(mx[ax], 0.0f), rmin[ax]);
                     }
+                    filter_cones[i * 8 + k] = leaf_cone_word(n.indexes[k], n.leaf_size[k]);
                 }
     }
 };

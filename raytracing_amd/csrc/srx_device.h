@@ -14,7 +14,11 @@
 //           times, padded, tell whether the ray can hit the leaf at all: if not, the leaf is not pushed (2.4 packet
 //           tests per ray). Results, visiting order and node tests are the reference's.
 //           Line A: 8 x {min.x, min.y, min.z, max.x}; line B: 8 x
-//           {max.y, max.z, link, 0}; link == 0 => unused child slot (the root is never a child).
+//           {max.y, max.z, link, cone}; link == 0 => unused child slot (the root is never a child).
+//           cone (leaf guard, SRX_LINK_EXT children only, else 0): bytes 0-2 = a as int8, the leaf's mean triangle
+//           normal scaled to a largest component of +-127, byte 3 = h: the leaf may be skipped only by a ray with
+//           |a . dq| >= 127 h (dq = unit direction x 127 as int8: one v_dot4), i.e. one that is not close to the plane
+//           of any of the leaf's triangles (h = 255: never).
 //           One octet (8 adjacent lanes = the reference's 8 AVX lanes, BVH.h:874-881) reads a node with
 //           two dwordx4 loads per lane, each load covering one contiguous 128-B line per octet.
 //   GPacket 384 B = three 128-B lines: 8 x {p1.x,p1.y,p1.z,e1.x} | 8 x {e1.y,e1.z,e2.x,0} |
@@ -38,6 +42,9 @@
 #define SRX_SPILL_SLOTS 16384u               // > 8 192 = the wave slots of the chip: a free area always exists
 #define SRX_SPILL_MIN_LDS_DEPTH 16           // half the LDS part moves at a time and a node pushes up to 8 entries
 #define SRX_LINK_EXT 0x40000000u             // leaf child whose reference box = tight planes stored here, grown to the origin
+#define SRX_FILTER_PAD_REL 5.0e-4f           // leaf filter: a leaf's box is padded by this x the largest coordinate distance from the ray's origin to the box ...
+#define SRX_FILTER_PAD_ABS 4.0e-6f           // ... + this x (scene size + largest |origin coordinate|), for the rounding of the slab test itself
+#define SRX_CONE_NEVER 0xFF000000u           // leaf guard word: this leaf is never skipped (255 x 127 > any |a . dq|)
 
 struct GNode { float4 a[8]; float4 b[8]; };
 struct GPacket { float4 a[8]; float4 b[8]; float2 c[8]; uint32_t material[8]; uint32_t tri_index[8]; };
@@ -87,7 +94,7 @@ struct GScene {
     // trees): SRX_SPILL_SLOTS areas of 8 x stack_depth entries, one per wave that ever spills, claimed with an atomic.
     unsigned long long* spill_area;
     uint32_t* spill_ctl;          // [0] claim cursor, [1] error flag (no free area), [2] spills so far, [16 + i] area i taken
-    float filter_pad;             // leaf filter: planes are pushed out by this distance (1e-4 of the scene's size)
+    float filter_pad;             // leaf filter: SRX_FILTER_PAD_ABS x the scene's size (the absolute part of the pad); inf: filter off
 };
 
 // ---- ray / hit / shadow records of the wavefront queues --------------------

@@ -6,6 +6,7 @@
 // and the worst-case traversal stack depth of the tree computed so kernels can size their LDS stack.
 #include "srx_host.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 
@@ -97,6 +98,54 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
             }
         }
     };
+    // ---- leaf guard: the normal-cone word of the leaf made of packets [first, first + count) (srx_device.h, GNode).
+    // The reference's fp32 Moller-Trumbore (Primitives.h:159-202) divides by a det that is mostly rounding error when a
+    // ray runs closer than asin(kappa / sin(gamma)) to a triangle's plane (gamma = angle between the edges), and may then
+    // accept a "hit" far outside the triangle: the filter may skip a leaf only for rays that keep that distance from the
+    // planes of ALL its triangles. kappa: DESIGN.md section 5 derives |ray - hit| <= 33 u |o - p1| / (sin(gamma) |cos(phi)|)
+    // (u = 2^-24) for an accepted hit; with the filter's pad of SRX_FILTER_PAD_REL x the coordinate distance from the origin
+    // to the leaf's box (>= |o - p1| / sqrt 3) that is kappa >= 0.0069, taken as 1/80.
+    auto cone_word = [&](uint32_t first, uint32_t count) -> uint32_t {
+        const double kappa = 1.0 / 80.0;
+        struct V { double x, y, z; };
+        std::vector<V> nh; std::vector<double> tau;
+        V sum = {0, 0, 0};
+        for (uint32_t p = first; p < first + count; p++) {
+            const uint8_t* pk = rp + (size_t)p * SRX_REF_PACKET_BYTES;
+            const int size = (int)(int8_t)pk[420];
+            for (int k = 0; k < 8 && k < size; k++) {
+                const double ax = rdf(pk, 96 + 4 * k), ay = rdf(pk, 128 + 4 * k), az = rdf(pk, 160 + 4 * k);
+                const double bx = rdf(pk, 192 + 4 * k), by = rdf(pk, 224 + 4 * k), bz = rdf(pk, 256 + 4 * k);
+                const double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+                const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+                const double ll = std::sqrt(ax * ax + ay * ay + az * az) * std::sqrt(bx * bx + by * by + bz * bz);
+                if (!(ll >= 1e-16) || !(ll <= 1e16) || !(nn > 0.0)) return SRX_CONE_NEVER;
+                const double t = kappa / (nn / ll);
+                if (!(t < 1.0)) return SRX_CONE_NEVER;
+                V n = {nx / nn, ny / nn, nz / nn};
+                if (!nh.empty() && n.x * nh[0].x + n.y * nh[0].y + n.z * nh[0].z < 0.0) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
+                nh.push_back(n); tau.push_back(t);
+                sum.x += n.x; sum.y += n.y; sum.z += n.z;
+            }
+        }
+        if (nh.empty()) return 0u;
+        const double m = std::max(std::fabs(sum.x), std::max(std::fabs(sum.y), std::fabs(sum.z)));
+        if (!(m > 1e-6)) return SRX_CONE_NEVER;
+        const double a[3] = {std::floor(sum.x / m * 127.0 + 0.5), std::floor(sum.y / m * 127.0 + 0.5), std::floor(sum.z / m * 127.0 + 0.5)};
+        const double A = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        double thr = 0.0;
+        for (size_t k = 0; k < nh.size(); k++) {
+            const double c = std::fabs(nh[k].x * a[0] + nh[k].y * a[1] + nh[k].z * a[2]) / A;
+            if (!(tau[k] < c)) return SRX_CONE_NEVER;
+            const double sn = std::sqrt(std::max(0.0, 1.0 - c * c));
+            thr = std::max(thr, tau[k] * c + std::sqrt(1.0 - tau[k] * tau[k]) * sn);
+        }
+        // the kernel tests |a . dq| >= 127 h with dq = the ray's unit direction x 127 rounded to int8: |a . dq - 127 a . d^|
+        // <= (|ax| + |ay| + |az|) / 2, hence the second term
+        const double h = std::ceil(thr * A + (std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2])) / 254.0 + 0.01);
+        if (!(h <= 254.0)) return SRX_CONE_NEVER;
+        return ((uint32_t)(int)a[0] & 255u) | (((uint32_t)(int)a[1] & 255u) << 8) | (((uint32_t)(int)a[2] & 255u) << 16) | ((uint32_t)(int)h << 24);
+    };
     float scene_scale = 1e-3f;
     if (desc->n_packets) {
         float mn[3], mx[3];
@@ -104,7 +153,10 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
         for (int ax = 0; ax < 3; ax++)
             if (mx[ax] >= mn[ax]) scene_scale = std::max(scene_scale, std::max(mx[ax] - mn[ax], std::max(std::fabs(mn[ax]), std::fabs(mx[ax]))));
     }
-    s->g.filter_pad = 1e-4f * scene_scale;
+    s->g.filter_pad = SRX_FILTER_PAD_ABS * scene_scale;
+    // SRX_LEAF_FILTER=0: no leaf is ever skipped (an infinite pad), i.e. the reference's walk packet for packet; for A/B
+    // runs of the filter (tests/test_leaf_filter_gpu.py)
+    if (const char* e = getenv("SRX_LEAF_FILTER")) if (atoi(e) == 0) s->g.filter_pad = __builtin_inff();
 
     // ---- nodes: 288-B SoA record (BVH.h:874-881) -> two 128-B child-major lines
     std::vector<GNode> nodes(desc->n_nodes);
@@ -131,7 +183,9 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
             // an ordering the clamp keeps); a non-zero reference plane IS the tight plane.
             bool ext = leaf > 0;
             for (int ax = 0; ax < 3 && ext; ax++) ext = (rmin[ax] <= 0.0f) && (rmax[ax] >= 0.0f);
+            uint32_t cone = 0u;
             if (ext) {
+                cone = cone_word(idx, leaf);
                 float pmn[3], pmx[3];
                 packet_bounds(idx, leaf, pmn, pmx);
                 for (int ax = 0; ax < 3; ax++) {
@@ -142,7 +196,7 @@ extern "C" int srx_scene_create(const srx_scene_desc* desc, srx_scene** out) {
                 link |= SRX_LINK_EXT;
             }
             nodes[i].a[k] = make_float4(smin[0], smin[1], smin[2], smax[0]);
-            nodes[i].b[k] = make_float4(smax[1], smax[2], u2f_host(link), 0.0f);
+            nodes[i].b[k] = make_float4(smax[1], smax[2], u2f_host(link), u2f_host(cone));
         }
     }
     // ---- packets: 448-B record (Primitives.h:127-134) -> three 128-B lanes-major lines

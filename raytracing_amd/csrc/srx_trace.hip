@@ -45,7 +45,7 @@
 // (bound 32: every ray is long, the pool has little to even out and the check is pure cost), and launches under 4 x
 // 8 192 waves of 64 rays lose more to the longer waves' tail than they gain. Hence: trees with a bound of at least 40,
 // launches of at least 2.1 M rays (SRX_K8_ROUNDS, swept 1-16 on both scenes).
-#define SRX_SPILL_LDS_DEPTH 24
+#define SRX_SPILL_LDS_DEPTH 20
 #define SRX_SPILL_MIN_BOUND 40
 
 
@@ -108,6 +108,7 @@ __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max_neg(float a, float b) { float r; asm("v_max_f32 %0, -%1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }   // max(-a, b)
 __device__ __forceinline__ float x86_min(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float x86_max(float a, float b) { return a > b ? a : b; }
 
@@ -118,11 +119,17 @@ __device__ __forceinline__ float x86_max(float a, float b) { return a > b ? a : 
 // stored one or 0, and 0 lies between the stored planes or beyond them on the side the stored plane was clamped from;
 // fma(x, 1/d, -o/d) is monotone in x, so the reference's slab interval is [min(near, z), max(far, z)] with
 // z = fma(0, 1/d, -o/d), which is -o/d itself up to the sign of a zero (a zero result is "no hit" either way).
-//   Filter: the stored box's interval, widened by pt = pad * max|1/d| on both ends (pt2 = 2 pt, npt = -pt), must not
-// be empty or behind the ray. An inner child that the reference test accepts always passes it.
+//   Filter: a leaf is skipped (may_hit false) when BOTH hold: (1) the stored box's interval, widened by pt on both
+// ends, is empty or behind the ray, with pt = SRX_FILTER_PAD_REL x the largest coordinate distance from the ray's origin
+// to the box (max|t_plane| |d_axis|, in units of t: c1 = SRX_FILTER_PAD_REL max|1/d|) + floor_t, the absolute part
+// (SRX_FILTER_PAD_ABS x (scene size + max|o|) max|1/d|; infinite for rays that are never filtered); (2) the ray keeps clear of the planes of
+// all the leaf's triangles, |a . dq| >= 127 h with the leaf's cone word (srx_device.h): near such a plane the
+// reference's triangle test divides by a det that is rounding noise and can accept far outside the padded box
+// (tests/test_leaf_filter_*.py). An inner child that the reference test accepts always passes (1)
+// and its cone word is 0 (a = 0, h = 0: (2) holds trivially).
 template <bool FAST>
-__device__ __forceinline__ uint32_t node_test(const float4 A, const float3 B, const f3 inv, const f3 fused,
-                                              const float pt2, const float npt, bool& may_hit) {
+__device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, const f3 inv, const f3 fused, const f3 d, const int dq,
+                                              const float c1, const float floor_t, bool& may_hit) {
     const float tx1 = __fmaf_rn(A.x, inv.x, fused.x), tx2 = __fmaf_rn(A.w, inv.x, fused.x);
     const float ty1 = __fmaf_rn(A.y, inv.y, fused.y), ty2 = __fmaf_rn(B.x, inv.y, fused.y);
     const float tz1 = __fmaf_rn(A.z, inv.z, fused.z), tz2 = __fmaf_rn(B.y, inv.z, fused.z);
@@ -130,7 +137,17 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float3 B, co
     const float nx = hw_min(tx1, tx2), ny = hw_min(ty1, ty2), nz = hw_min(tz1, tz2);
     const float fx = hw_max(tx1, tx2), fy = hw_max(ty1, ty2), fz = hw_max(tz1, tz2);
     const float smin = hw_max3(nz, ny, nx), smax = hw_min3(fz, fy, fx);
-    may_hit = !(smin - smax > pt2) && !(smax < npt);
+    // guard: int8 dot of the leaf's axis with the ray's quantised direction (byte 3 of dq is 0, so h drops out of it)
+#if defined(SRX_EXP_B3) || defined(SRX_EXP_NOGUARD)
+    const bool clear_of_planes = true;   // experiment builds only (unsound): what the guard costs
+#else
+    const uint32_t cone = f2u(B.w);
+    const int sd = __builtin_amdgcn_sdot4((int)cone, dq, 0, false);
+    const bool clear_of_planes = (uint32_t)abs(sd) >= (cone >> 24) * 127u;
+#endif
+    const float ex = hw_max_neg(nx, fx) * (fabsf(d.x) * c1), ey = hw_max_neg(ny, fy) * (fabsf(d.y) * c1), ez = hw_max_neg(nz, fz) * (fabsf(d.z) * c1);
+    const float pt = hw_max3(ez, ey, ex) + floor_t;
+    may_hit = (!(smin - smax > pt + pt) && !(smax < -pt)) || !clear_of_planes;
     float tmin, tmax;
     if (FAST) {
         const float emin = hw_max3(hw_min(nz, fused.z), hw_min(ny, fused.y), hw_min(nx, fused.x));
@@ -182,8 +199,8 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     // ray j of this octet; the block's rays are contiguous in the queue
     const uint32_t ray0 = lblock * SRX_RAYS_PER_BLOCK + oct;
     const uint32_t n_rays = a.n;
-    float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {o, d.x}, {d.yz, inv.xy}, {inv.z, fused}
-    float* const s_pt = (float*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening
+    float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {d, o.x}, {o.yz, inv.xy}, {inv.z, fused}
+    float2* const s_pt = (float2*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening, quantised direction (bits)
     uint32_t* const s_spilled = (uint32_t*)(s_pt + K * SRX_OCTETS_PER_BLOCK);   // [octets]: entries parked in memory (SPILL)
     // (LDS per wave = 64 B x stack depth + 1 792 B; 5 120 B is what 32 waves per CU can have)
 
@@ -210,15 +227,24 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         const bool finite6 = well_defined(sfused.x) && well_defined(sfused.y) && well_defined(sfused.z) &&
                              well_defined(sinv.x) && well_defined(sinv.y) && well_defined(sinv.z);
         fast = !__any(mine && !finite6);   // wave-uniform
-        // the leaf filter's widening of this ray's slab interval (node_test); infinite = never filtered, for a ray
-        // with a non-finite 1/d or -o/d component
-        const float spt = finite6 ? sc.filter_pad * fmaxf(fmaxf(fabsf(sinv.x), fabsf(sinv.y)), fabsf(sinv.z)) : __builtin_inff();
+        // the absolute part of the leaf filter's widening of this ray's slab interval (node_test): (filter_pad +
+        // SRX_FILTER_PAD_ABS * max|o|) * max|1/d|; infinite = never filtered, for a ray with a non-finite 1/d or -o/d
+        // component, a direction whose squared length leaves [1e-12, 1e12] or one with a component below 1e-15 |d| (the
+        // guard and the relative part of the widening need them in range)
+        const float sdd = __fmaf_rn(sd.z, sd.z, __fmaf_rn(sd.y, sd.y, sd.x * sd.x));
+        const float sdmin = fminf(fminf(fabsf(sd.x), fabsf(sd.y)), fabsf(sd.z));
+        const float spad = __fmaf_rn(SRX_FILTER_PAD_ABS, fmaxf(fmaxf(fabsf(so.x), fabsf(so.y)), fabsf(so.z)), sc.filter_pad);
+        const float spt = (finite6 && sdd >= 1e-12f && sdd <= 1e12f && sdmin * sdmin >= 1e-30f * sdd)
+                              ? spad * fmaxf(fmaxf(fabsf(sinv.x), fabsf(sinv.y)), fabsf(sinv.z)) : __builtin_inff();
+        // the guard's quantised direction: round(127 d / |d|) as three int8 (anything when spt is infinite: never used)
+        const float sq = 127.0f / sqrtf(sdd);
+        const uint32_t sdq = ((uint32_t)(int)rintf(sd.x * sq) & 255u) | (((uint32_t)(int)rintf(sd.y * sq) & 255u) << 8) | (((uint32_t)(int)rintf(sd.z * sq) & 255u) << 16);
         if (sub < K) {
             float4* dst = s_setup + ((size_t)sub * SRX_OCTETS_PER_BLOCK + oct) * 3;
-            dst[0] = make_float4(so.x, so.y, so.z, sd.x);
-            dst[1] = make_float4(sd.y, sd.z, sinv.x, sinv.y);
+            dst[0] = make_float4(sd.x, sd.y, sd.z, so.x);
+            dst[1] = make_float4(so.y, so.z, sinv.x, sinv.y);
             dst[2] = make_float4(sinv.z, sfused.x, sfused.y, sfused.z);
-            s_pt[sub * SRX_OCTETS_PER_BLOCK + oct] = spt;
+            s_pt[sub * SRX_OCTETS_PER_BLOCK + oct] = make_float2(spt, u2f(sdq));
         }
     }
     // the block's rays that exist are j = 0 .. block_rays-1 (ray j was set up by lane j / 8 of octet j % 8); octet o starts
@@ -235,13 +261,15 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     // few trips that need them (packet tests, results): fewer loop-carried registers
     f3 inv, fused;
     const float4* ray_setup = s_setup;
-    float pt2 = 0.0f, npt = 0.0f;
+    float c1 = 0.0f, floor_t = 0.0f;
+    int dq = 0;
     auto load_ray_j = [&](int j) {
         ray_setup = s_setup + (size_t)j * 3;
         const float2 r1 = *(const float2*)((const char*)ray_setup + 24);
         const float4 r2 = ray_setup[2];
-        const float pt = s_pt[j];
-        pt2 = pt + pt; npt = -pt; inv = f3(r1.x, r1.y, r2.x); fused = f3(r2.y, r2.z, r2.w);
+        const float2 pq = s_pt[j];
+        floor_t = pq.x; dq = (int)f2u(pq.y); inv = f3(r1.x, r1.y, r2.x); fused = f3(r2.y, r2.z, r2.w);
+        c1 = SRX_FILTER_PAD_REL * fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
     };
     load_ray_j(oct);
 
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 if (a.advanced_org3) {
                     const float4 r0 = ray_setup[0];
                     const float2 r1 = *(const float2*)(ray_setup + 1);
-                    const f3 o(r0.x, r0.y, r0.z), d(r0.w, r1.x, r1.y);
+                    const f3 o(r0.w, r1.x, r1.y), d(r0.x, r0.y, r0.z);
                     const f3 p = o + (best_t * d) * 0.999f;
                     a.advanced_org3[3 * (size_t)r] = p.x; a.advanced_org3[3 * (size_t)r + 1] = p.y; a.advanced_org3[3 * (size_t)r + 2] = p.z;
                 }
@@ -308,13 +336,20 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             const uint32_t off = (link << 7) | sub16;
             const char* const rec = sc.geom + (size_t)off;
             const float4 A = *(const float4*)rec;
-            const float3 B = *(const float3*)(rec + 128);   // 12 of the slot's 16 bytes: {max.y, max.z, link} / {e1.y, e1.z, e2.x}
+#ifdef SRX_EXP_B3
+            const float3 B3 = *(const float3*)(rec + 128);
+            const float4 B = make_float4(B3.x, B3.y, B3.z, 0.0f);
+#else
+            const float4 B = *(const float4*)(rec + 128);   // {max.y, max.z, link, cone} / {e1.y, e1.z, e2.x, 0}
+#endif
+            const float4 r0 = ray_setup[0];                 // the ray's direction (and o.x): both kinds of trip need it
+            const f3 d(r0.x, r0.y, r0.z);
             __builtin_amdgcn_s_setprio(0);
             if (!leaf) {
                 n_nodes++;
                 bool may_hit;
-                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused, pt2, npt, may_hit)
-                                         : node_test<false>(A, B, inv, fused, pt2, npt, may_hit);
+                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused, d, dq, c1, floor_t, may_hit)
+                                         : node_test<false>(A, B, inv, fused, d, dq, c1, floor_t, may_hit);
                 // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id. result==0 (either sign) is "no hit";
                 // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86): both together are
                 // |result| > (lane == 0 ? 7 : 0)
@@ -343,9 +378,8 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 // The rest of a multi-packet leaf goes back on top with distance -inf: it is never culled, exactly
                 // like the reference's inner `for` over the leaf's packets (Core.h:179).
                 const float2 C = *(const float2*)(rec + 256 - 8 * sub);   // third line: 8 x {e2.y, e2.z}, 8-B slots
-                const float4 r0 = ray_setup[0];
                 const float2 r1 = *(const float2*)(ray_setup + 1);
-                const f3 o(r0.x, r0.y, r0.z), d(r0.w, r1.x, r1.y);
+                const f3 o(r0.w, r1.x, r1.y);
                 if ((link & (SRX_LINK_MORE_MAX << SRX_LINK_MORE_SHIFT)) != 0u) {
                     sp++;   // next packet of the leaf: line + 3, one packet fewer to follow
                     if (sub == 0) s_stack[sp * SRX_OCTETS_PER_BLOCK + oct] = (0xFF800000ull << 32) | (link + 3u - (1u << SRX_LINK_MORE_SHIFT));
@@ -477,7 +511,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
 
 static size_t trace_lds_bytes(int lds_depth, int k, bool spill) {
     return (size_t)lds_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
-           (size_t)SRX_OCTETS_PER_BLOCK * k * (3 * sizeof(float4) + sizeof(float)) + (spill ? SRX_OCTETS_PER_BLOCK * sizeof(uint32_t) : 0);
+           (size_t)SRX_OCTETS_PER_BLOCK * k * (3 * sizeof(float4) + sizeof(float2)) + (spill ? SRX_OCTETS_PER_BLOCK * sizeof(uint32_t) : 0);
 }
 
 template <int K, bool SPILL>
@@ -493,9 +527,11 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
     // Rays per octet for a form of the kernel: the most whose LDS footprint lets 32 waves share a CU, fewer for a launch
     // that cannot fill the chip's 8 192 wave slots (256 CUs x 32) with that many (more waves, each a shorter serial
     // chain: the last generations of a pass are launches of a few thousand rays).
+    static const size_t lds_budget = [] { const char* e = getenv("SRX_LDS_BUDGET"); return (size_t)(e ? atoi(e) : (int)SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY); }();   // experiments
+    static const int spill_depth = [] { const char* e = getenv("SRX_SPILL_DEPTH"); return e ? (atoi(e) & ~1) : SRX_SPILL_LDS_DEPTH; }();   // experiments
     auto rays_per_octet = [&](int lds_depth, bool spill_form) {
         int k = SRX_RAYS_PER_OCTET_MAX;
-        while (k > 1 && trace_lds_bytes(lds_depth, k, spill_form) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) k >>= 1;
+        while (k > 1 && trace_lds_bytes(lds_depth, k, spill_form) > lds_budget) k >>= 1;
         static const uint64_t rounds8 = [] { const char* e = getenv("SRX_K8_ROUNDS"); return (uint64_t)(e ? atoi(e) : 4); }();
         while (k > 1 && (uint64_t)a.n < (k == 8 ? rounds8 : 1ull) * 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
         return k;
@@ -507,8 +543,8 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
     bool spill = false;
     int k = rays_per_octet(depth, false);
     if (sc.spill_area && sc.stack_depth >= SRX_SPILL_MIN_BOUND) {
-        const int ks = rays_per_octet(SRX_SPILL_LDS_DEPTH, true);
-        if (ks > k || trace_lds_bytes(depth, k, false) > SRX_LDS_PER_WAVE_FOR_FULL_OCCUPANCY) { depth = SRX_SPILL_LDS_DEPTH; spill = true; k = ks; }
+        const int ks = rays_per_octet(spill_depth, true);
+        if (ks > k || trace_lds_bytes(depth, k, false) > lds_budget) { depth = spill_depth; spill = true; k = ks; }
     }
     if (const char* e = getenv("SRX_LDS_STACK")) {
         const int forced_depth = atoi(e) & ~1;
