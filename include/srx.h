@@ -149,6 +149,17 @@ int srx_cast_closest(srx_scene* scene, const float* org3, const float* dir3, uin
                      float* advanced_org3, uint64_t* counters2);
 int srx_cast_closest_device(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, srx_hit* d_hits,
                             uint64_t* d_counters2, void* stream);
+/* srx_cast_closest_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc). NO COUNTERPART IN THE REFERENCE, whose casts use the CPU stack (Core.h:55-58).
+ * Same kernels and results as srx_cast_closest_device; what that call keeps in memory allocated with the scene (the
+ * traversal stack's overflow areas and their control words) and its counters (here replicated over 256 slots and folded
+ * into d_counters2 afterwards, so counting does not serialise on one word) live in a static device array of the
+ * library: 64.1 MB per GPU the library runs on, held until the process ends. Limit: scenes whose traversal stack bound
+ * (srx_scene_stack_bound) exceeds 64 entries are refused. Allocates nothing, frees nothing; asynchronous on `stream`.
+ * All calls on one GPU share that array: calls that overlap on one GPU (two streams, two threads) race. d_counters2
+ * (optional, device, zeroed by the caller) is added to, as in srx_cast_closest_device. */
+int srx_cast_closest_device_static(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, srx_hit* d_hits,
+                                   uint64_t* d_counters2, void* stream);
 /* replace `RayEngine::execute_lighting_cast(XYZ, Light*)` (Core.h:351-358) for sun lights:
  * lit[i] = 1 iff the closest hit along dir is farther than 9999 (Primitives.h:44-50). */
 int srx_cast_shadow(srx_scene* scene, const float* org3, const float* dir3, uint32_t n, uint8_t* lit);

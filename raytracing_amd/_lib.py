@@ -15,7 +15,7 @@ EXPORTS = [
     "srx_last_error", "srx_init",
     "srx_package_create", "srx_package_get", "srx_package_destroy", "srx_build_tables",
     "srx_scene_create", "srx_scene_destroy", "srx_scene_stack_bound", "srx_scene_stack_spills",
-    "srx_cast_closest", "srx_cast_closest_device", "srx_cast_shadow", "srx_cast_shadow_device",
+    "srx_cast_closest", "srx_cast_closest_device", "srx_cast_closest_device_static", "srx_cast_shadow", "srx_cast_shadow_device",
     "srx_renderer_create", "srx_renderer_destroy", "srx_renderer_set_timing",
     "srx_trace_pass", "srx_trace_pass_interleaved", "srx_trace_passes_interleaved", "srx_trace_pass_adaptive", "srx_process_rays", "srx_camera_rays",
     "srx_noise_create", "srx_noise_destroy", "srx_noise_error_map", "srx_noise_analyze", "srx_noise_regions", "srx_noise_priorities",

@@ -9,11 +9,47 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
+
+// ---- scratch of srx_cast_closest_device_static, the entry point that allocates nothing (include/srx.h): the traversal
+// stack's overflow areas (SRX_SPILL_SLOTS areas of 8 octets x SRX_STATIC_MAX_STACK entries), their control words and
+// the replicated traversal counters, in device memory that comes with the library's code object. Each GPU the library
+// runs on holds its own copy (64.1 MB) until the process ends. Host code uses the per-device address taken once with
+// hipGetSymbolAddress (static_scratch_for), never the array's name.
+#define SRX_STATIC_MAX_STACK 64
+#define SRX_STATIC_COUNTER_SLOTS 256
+struct StaticScratch {
+    unsigned long long area[(size_t)SRX_SPILL_SLOTS * 8 * SRX_STATIC_MAX_STACK];
+    uint32_t ctl[16 + SRX_SPILL_SLOTS];
+    unsigned long long counters[SRX_STATIC_COUNTER_SLOTS * 2];
+};
+static __device__ __align__(256) StaticScratch scratch;
 
 static thread_local std::string g_error;
 void srx_set_error(const std::string& s) { g_error = s; }
 
 extern "C" const char* srx_last_error(void) { return g_error.c_str(); }
+
+namespace {
+// Address of `scratch` on the CURRENT device: taken once per device (at srx_init, or at the first static call on a
+// device srx_init was not called for) and kept; every GPU has its own copy of the array at its own address.
+enum { SRX_MAX_DEVICES = 64 };
+StaticScratch* g_static_scratch[SRX_MAX_DEVICES];
+std::mutex g_static_mutex;
+
+int static_scratch_for(int device, StaticScratch** out) {
+    if (device < 0 || device >= SRX_MAX_DEVICES) SRX_FAIL("srx: device index beyond the 64 this library keeps static scratch for");
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!g_static_scratch[device]) {
+        void* p = nullptr;
+        SRX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) SRX_FAIL("srx: hipGetSymbolAddress returned no address for the static scratch");
+        g_static_scratch[device] = (StaticScratch*)p;
+    }
+    *out = g_static_scratch[device];
+    return 0;
+}
+}  // namespace
 
 extern "C" int srx_init(int device) {
     int n = 0;
@@ -25,7 +61,8 @@ extern "C" int srx_init(int device) {
     SRX_HIP(hipGetDeviceProperties(&p, device));
     if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
         SRX_FAIL(std::string("srx_init: kernels are built for gfx950 only, device is ") + p.gcnArchName);
-    return 0;
+    StaticScratch* sp = nullptr;
+    return static_scratch_for(device, &sp);
 }
 
 namespace {
@@ -360,6 +397,53 @@ extern "C" int srx_cast_closest_device(srx_scene* scene, const float* d_org3, co
     a.hits = (GHit*)d_hits;
     a.counters = (unsigned long long*)d_counters2;
     SRX_HIP(srx_launch_trace(0, scene->g, a, (hipStream_t)stream));
+    return 0;
+}
+
+// Folds the replicated counter slots of the static scratch into the caller's two counters.
+__global__ void k_fold_static_counters(const unsigned long long* slots, unsigned long long* out2) {
+    unsigned long long a = slots[2 * threadIdx.x], b = slots[2 * threadIdx.x + 1];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out2[0], a); atomicAdd(&out2[1], b); }
+}
+
+// srx_cast_closest_device for callers that cannot allocate (include/srx.h): same kernels; the traversal stack's overflow
+// areas, their control words and the replicated counter slots live in this library's static device scratch instead of
+// memory allocated with the scene. No hipMalloc / hipFree / allocating call on this path.
+extern "C" int srx_cast_closest_device_static(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, srx_hit* d_hits,
+                                              uint64_t* d_counters2, void* stream) {
+    if (!scene) SRX_FAIL("srx_cast_closest_device_static: null scene");
+    if (scene->g.stack_depth > SRX_STATIC_MAX_STACK)
+        SRX_FAIL("srx_cast_closest_device_static: the scene's traversal stack bound (" + std::to_string(scene->g.stack_depth) +
+                 ") exceeds the " + std::to_string(SRX_STATIC_MAX_STACK) + " entries per ray the static scratch holds; use srx_cast_closest_device");
+    int device = -1;
+    SRX_HIP(hipGetDevice(&device));
+    if (device != scene->device) SRX_FAIL("srx_cast_closest_device_static: the scene lives on another device than the current one");
+    StaticScratch* sp = nullptr;
+    if (static_scratch_for(device, &sp)) return 1;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    // what must start at zero: claim cursor, error flag, spill count and the "area taken" words (a wave releases its
+    // area when it ends, but a previous call may have been abandoned), and the counter slots
+    SRX_HIP(hipMemsetAsync(sp->ctl, 0, sizeof(sp->ctl), st));
+    if (d_counters2) SRX_HIP(hipMemsetAsync(sp->counters, 0, sizeof(sp->counters), st));
+    GScene g = scene->g;
+    g.spill_area = sp->area;
+    g.spill_ctl = sp->ctl;
+    TraceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.org = d_org3; a.org_stride = 3; a.dir = d_dir3; a.dir_stride = 3; a.n = n;
+    a.hits = (GHit*)d_hits;
+    if (d_counters2) { a.counters = sp->counters; a.counter_slot_mask = SRX_STATIC_COUNTER_SLOTS - 1; a.counter_slot_stride = 2; }
+    SRX_HIP(srx_launch_trace(0, g, a, st));
+    if (d_counters2) {
+        hipLaunchKernelGGL(k_fold_static_counters, dim3(1), dim3(SRX_STATIC_COUNTER_SLOTS), 0, st, sp->counters, (unsigned long long*)d_counters2);
+        SRX_HIP(hipGetLastError());
+    }
     return 0;
 }
 

@@ -1,0 +1,124 @@
+"""srx_cast_closest_device_static: the entry point that allocates nothing (include/srx.h), through the C-ABI.
+
+Its output must equal srx_cast_closest_device's bit for bit (hits and traversal counters) on two calls in a row, the
+second with a smaller input (the static scratch keeps the first call's contents). SRX_LDS_STACK=16 forces the traversal
+stack's overflow path on an ordinary scene, so the scratch's overflow areas are really used, not only its counter slots.
+Collected last (test_zz_*): the round's end runs pytest -x.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _cast(L, fn, scene, org, dirs, stream=None):
+    import torch
+    o = torch.from_numpy(org).cuda()
+    d = torch.from_numpy(dirs).cuda()
+    n = len(org)
+    hits = torch.zeros(n * 5, dtype=torch.int32, device="cuda")
+    ctr = torch.zeros(2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rc = fn(scene, C.c_void_p(o.data_ptr()), C.c_void_p(d.data_ptr()), C.c_uint32(n), C.c_void_p(hits.data_ptr()),
+            C.c_void_p(ctr.data_ptr()), C.c_void_p(stream))
+    assert rc == 0, L.srx_last_error().decode()
+    torch.cuda.synchronize()
+    return hits.cpu().numpy().reshape(n, 5), ctr.cpu().numpy()
+
+
+@pytest.mark.parametrize("lds_stack", [None, "16"])
+def test_static_cast_equals_device_cast(tables, monkeypatch, lds_stack):
+    import torch
+    from raytracing_amd import engine, scenes, _lib
+    L = _lib.lib()
+    desc = scenes.atrium(32768, res=(160, 90), subdiv=2, tex_size=64)
+    PS = engine.package(desc, tables=tables)
+    RE = engine.RayEngine(0)
+    RE.load_scene(PS)
+    assert 16 < RE.stack_bound() <= 64
+    if lds_stack is not None:
+        monkeypatch.setenv("SRX_LDS_STACK", lds_stack)
+    ext = float(np.abs(desc.tris["p"]).max())
+    before = torch.cuda.memory_allocated()
+    for n, seed in ((600_000, 21), (70_001, 22), (0, 23)):            # two calls in a row, the second smaller; then an empty one
+        org, dirs = random_rays(max(n, 1), seed=seed, extent=ext)
+        org, dirs = org[:n], dirs[:n]
+        if n == 0:
+            rc = L.srx_cast_closest_device_static(RE.scene, None, None, C.c_uint32(0), None, None, None)
+            assert rc == 0
+            continue
+        h_ref, c_ref = _cast(L, L.srx_cast_closest_device, RE.scene, org, dirs)
+        h_new, c_new = _cast(L, L.srx_cast_closest_device_static, RE.scene, org, dirs)
+        assert np.array_equal(h_new, h_ref)                             # material, t, u, v, tri_index: all bits
+        assert np.array_equal(c_new, c_ref) and c_ref[0] > 0
+        assert (h_ref[:, 0] != -1).any()
+    assert torch.cuda.memory_allocated() == before
+    RE.close()
+
+
+def _chain_scene(levels):
+    """A hand-made package: a chain of `levels` nodes, each with one inner child (slot 0) and seven one-triangle leaves,
+    so the worst-case traversal stack is 7 * (levels - 1) + 8 entries."""
+    from raytracing_amd import engine, scenes
+    n_nodes = levels
+    n_packets = 7 * (levels - 1) + 8
+    nodes = np.zeros((n_nodes, 72), np.uint32)
+    fl = nodes.view(np.float32)
+    packets = np.zeros((n_packets, 112), np.uint32)
+    pf = packets.view(np.float32)
+    tris = np.zeros((n_packets, 49), np.float32)
+    p = 0
+    for i in range(n_nodes):
+        for k in range(8):
+            inner = k == 0 and i + 1 < n_nodes
+            fl[i, 0 + k] = fl[i, 8 + k] = fl[i, 16 + k] = 2.0          # max x y z
+            fl[i, 24 + k] = fl[i, 32 + k] = fl[i, 40 + k] = -2.0       # min x y z
+            if inner:
+                nodes[i, 56 + k] = i + 1                               # indexes[k], leaf_size 0
+            else:
+                nodes[i, 48 + k] = 1                                   # leaf_size: one packet
+                nodes[i, 56 + k] = p
+                z = 0.1 + 0.01 * p
+                pf[p, 0], pf[p, 8], pf[p, 16] = -1.0, -1.0, z          # p1 of lane 0
+                pf[p, 24], pf[p, 32], pf[p, 40] = 4.0, 0.0, 0.0        # p1p2
+                pf[p, 48], pf[p, 56], pf[p, 64] = 0.0, 4.0, 0.0        # p1p3
+                packets[p, 104] = p                                    # index
+                packets.view(np.uint8)[p, 420] = 1                     # size
+                p += 1
+        nodes[i, 64], nodes[i, 65] = np.uint32(max(i - 1, 0)), i
+    assert p == n_packets
+    mats = np.array([scenes.material()])
+    return engine.PackagedScene(nodes.view(np.uint8).reshape(n_nodes, 288), packets.view(np.uint8).reshape(n_packets, 448),
+                                tris.view(np.uint8).reshape(n_packets, 196), mats, max_generations=1)
+
+
+def test_static_cast_refuses_a_tree_beyond_its_limit(tables):
+    """A chain of 12 nodes has a worst-case stack of 85 entries: more than the 64 per ray the static scratch holds."""
+    import torch
+    from raytracing_amd import engine, _lib
+    L = _lib.lib()
+    RE = engine.RayEngine(0)
+    o = torch.tensor([0.0, 0.0, -1.0], device="cuda"); d = torch.tensor([0.01, 0.02, 1.0], device="cuda")
+    h = torch.zeros(10, dtype=torch.int32, device="cuda")
+    for levels, ok in ((12, False), (8, True)):
+        PS = _chain_scene(levels)
+        PS.tables = tables
+        RE.load_scene(PS)
+        assert (RE.stack_bound() > 64) == (not ok)
+        rc = L.srx_cast_closest_device_static(RE.scene, C.c_void_p(o.data_ptr()), C.c_void_p(d.data_ptr()), C.c_uint32(1),
+                                              C.c_void_p(h.data_ptr()), None, None)
+        torch.cuda.synchronize()
+        if ok:
+            assert rc == 0, L.srx_last_error().decode()
+            rc2 = L.srx_cast_closest_device(RE.scene, C.c_void_p(o.data_ptr()), C.c_void_p(d.data_ptr()), C.c_uint32(1),
+                                            C.c_void_p(h.data_ptr() + 20), None, None)
+            torch.cuda.synchronize()
+            hh = h.cpu().numpy()
+            assert rc2 == 0 and np.array_equal(hh[:5], hh[5:]) and hh[0] == 0          # hit: material 0
+        else:
+            assert rc != 0 and b"exceeds the 64 entries" in L.srx_last_error()
+    RE.close()
