@@ -245,6 +245,16 @@ int srx_process_rays(srx_renderer* r, const float* org3, const float* dir3, cons
 int srx_camera_rays(const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h, uint32_t pass_index,
                     uint64_t seed, float* dir3, uint64_t* keys);
 
+/* The same with the REFERENCE's generator (`XorGen`, XorRandom.cpp:3-69, 119-132; `thread_local XorGen gen`, commons.cpp:30):
+ * ONE sequential stream seeded with seed4 (XorGen::seed), two `fRand` draws per pixel (Camera.h:95), pixels in row-major
+ * order of the rectangle: what one reference thread draws when it walks the rectangle. These are the parity ray sets of
+ * fixed XorRandom seeds; the renderer itself draws from per-ray keyed streams. At most 2^22 rays. */
+int srx_camera_rays_xorgen(const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h, uint32_t pass_index,
+                           const uint64_t* seed4, float* dir3);
+/* Raw streams of that generator, computed on the device: n_pools x `regen_pool` (8 floats each, XorRandom.cpp:35-69), then
+ * n_scalar x `fRand(0, 1)` (:128-132), from one XorGen seeded with seed4. For parity tests of the generator. */
+int srx_xorgen_stream(const uint64_t* seed4, uint32_t n_pools, uint32_t n_scalar, float* pools8, float* scalars);
+
 /* ---- device buffers for a host without a HIP toolchain. The reference keeps its framebuffers on the host
  * (SceneManager::raw_output / aux_output, SceneManager.h:288-289, filled at :370-380); here they live on the device as
  * res_x * res_y float4 {running mean r, g, b, sample count}. srx_buffer_create returns zeroed device memory (a

@@ -181,6 +181,30 @@ def camera_rays_keyed(camera, rect, pass_index, seed):
     return d, k
 
 
+def camera_rays_xorgen(camera, rect, pass_index, seed4=(1, 2, 3, 4)):
+    """Primaries of a rectangle, row-major, jitter from ONE sequential XorGen seeded with seed4."""
+    cam = np.ascontiguousarray(camera)
+    x0, y0, w, h = rect
+    d = np.zeros((w * h, 3), np.float32)
+    s4 = np.asarray(seed4, np.uint64)
+    lib().sro_camera_rays_xorgen(_p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w), C.c_int32(h), C.c_uint32(pass_index), _p(s4), _p(d))
+    return d
+
+
+def first_bounce_rays(S, org, dirs, seed4=(5, 6, 7, 8), capacity=None):
+    """Child rays queued by generation-0 `process_ray` calls in reference mode (one sequential XorGen seeded with
+    seed4, Core.h:498-591, :573-588): (origins, directions, parent index, total queued)."""
+    org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+    dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    cap = int(capacity if capacity is not None else 40 * len(org))
+    co = np.zeros((cap, 3), np.float32); cd = np.zeros((cap, 3), np.float32); par = np.zeros(cap, np.uint32)
+    n = C.c_uint32(0)
+    s4 = np.asarray(seed4, np.uint64)
+    S._chk(S.L.sro_first_bounce_rays(S.h, _p(org), _p(dirs), C.c_uint32(len(org)), _p(s4), C.c_uint32(cap), _p(co), _p(cd), _p(par), C.byref(n)))
+    m = min(cap, n.value)
+    return co[:m], cd[:m], par[:m], n.value
+
+
 def xorgen_stream(seed4, n_scalar, n_pools):
     s = np.asarray(seed4, np.uint64)
     sc = np.zeros(n_scalar, np.float32); po = np.zeros((n_pools, 8), np.float32); raw = np.zeros(4, np.uint64)

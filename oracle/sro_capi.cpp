@@ -268,6 +268,56 @@ int sro_camera_rays_keyed(const sro_camera_in* c, int32_t x0, int32_t y0, int32_
     return 0;
 }
 
+// Parity ray sets of fixed XorRandom seeds. Primaries: Camera::random_slope_at over the rectangle in row-major
+// order with ONE sequential XorGen seeded with seed4 (two fRand draws per pixel, Camera.h:95).
+int sro_camera_rays_xorgen(const sro_camera_in* c, int32_t x0, int32_t y0, int32_t w, int32_t hgt, uint32_t pass_index,
+                           const uint64_t* seed4, float* dir3) {
+    Camera cam = make_camera(c);
+    XorGen g; g.seed(seed4[0], seed4[1], seed4[2], seed4[3]);
+    size_t k = 0;
+    for (int y = y0; y < y0 + hgt; y++)
+        for (int x = x0; x < x0 + w; x++, k++) {
+            XYZ d = cam.random_slope_at(x, y, (int)(pass_index % (uint32_t)(c->subdiv * c->subdiv)), g);
+            dir3[3 * k] = d.X; dir3[3 * k + 1] = d.Y; dir3[3 * k + 2] = d.Z;
+        }
+    return 0;
+}
+// First-bounce rays: process_ray in REFERENCE mode (one sequential XorGen seeded with seed4 shared by all n primaries,
+// the recursive estimator's own queue, Core.h:498-591) on generation-0 rays; the child rays each call queues
+// (Core.h:573-588: position, slope) are written out, at most `capacity` of them, parent[i] = index of the primary.
+// *n_children = how many were queued in all.
+int sro_first_bounce_rays(void* hv, const float* org3, const float* dir3, uint32_t n, const uint64_t* seed4, uint32_t capacity,
+                          float* child_org3, float* child_dir3, uint32_t* parent, uint32_t* n_children) {
+    Handle* h = (Handle*)hv;
+    RayEngine RE; RE.data = &h->scene; RE.keyed = false;
+    XorGen xg; xg.seed(seed4[0], seed4[1], seed4[2], seed4[3]);
+    RE.shared_gen = &xg;
+    std::vector<PackagedRay> q;
+    RE.capture_first_bounce = &q;
+    Diagnostics st;
+    uint32_t total = 0;
+    try {
+        for (uint32_t i = 0; i < n; i++) {
+            PackagedRay r;
+            r.position = XYZ(org3[3 * i], org3[3 * i + 1], org3[3 * i + 2]);
+            r.slope = XYZ(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]);
+            r.generation = 0;
+            q.clear();
+            (void)RE.process_ray(st, r);
+            for (const PackagedRay& c : q) {
+                if (total < capacity) {
+                    child_org3[3 * total] = c.position.X; child_org3[3 * total + 1] = c.position.Y; child_org3[3 * total + 2] = c.position.Z;
+                    child_dir3[3 * total] = c.slope.X; child_dir3[3 * total + 1] = c.slope.Y; child_dir3[3 * total + 2] = c.slope.Z;
+                    parent[total] = i;
+                }
+                total++;
+            }
+        }
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+    *n_children = total;
+    return 0;
+}
+
 // One sample pass over a pixel rectangle, accumulated with the running-mean contract
 // (SceneManager.h:204-236). accum4/aux4 are res_x*res_y float4 = (r,g,b,sample count).
 //   mode 0: keyed RNG (what the GPU renderer computes; non-finite samples are skipped)

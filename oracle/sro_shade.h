@@ -205,6 +205,9 @@ struct RayEngine {
     const Scene* data = nullptr;
     Rng* shared_gen = nullptr;              // reference mode: one sequential stream (commons.cpp:30)
     bool keyed = false;                     // wavefront mode: per-ray KeyedGen seeded from ray.key
+    // parity ray sets: when set, a generation-0 call appends the child rays it queued (Core.h:573-588) and
+    // returns without tracing them
+    std::vector<PackagedRay>* capture_first_bounce = nullptr;
 
     MaterialSample sample_UV(const Material& m, float U, float V, Diagnostics& st) const {  // Materials.h:346-357
         MaterialSample s;
@@ -357,6 +360,10 @@ struct RayEngine {
             if (keyed) ray.key = local.child_key();
             r_queue.push_back(ray);
             throughput = XYZ(1, 1, 1);
+        }
+        if (capture_first_bounce && ray_data.generation == 0) {
+            capture_first_bounce->insert(capture_first_bounce->end(), r_queue.begin(), r_queue.end());
+            return aggregate;
         }
         for (size_t i = 0; i < r_queue.size(); i++) {                        // :592-598
             PackagedRay& ray = r_queue[i];

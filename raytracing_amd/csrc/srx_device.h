@@ -218,3 +218,40 @@ struct KeyedGen {
         return lo + f * (hi - lo);
     }
 };
+
+// ---- the reference's own generator (XorRandom.cpp:3-69, 119-132): xoshiro256+ scalar stream (`s0 + s3`) and the
+// 4-lane pool whose output word is `s0 + s1`. One sequential stream: the renderer does not draw from it (section 3 of
+// DESIGN.md); it defines the parity ray sets of fixed XorRandom seeds (srx_camera_rays_xorgen, srx_xorgen_stream).
+struct XorGen {
+    uint64_t s[4];
+    uint64_t S[4][4];        // S[word][lane] = xe_seed_AVX[word], 64-bit lane `lane`
+    float pool[8];
+    __device__ __forceinline__ static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    __device__ __forceinline__ uint64_t xe_next() {                          // :19-34
+        const uint64_t result = s[0] + s[3];
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return result;
+    }
+    __device__ __forceinline__ void seed(uint64_t n1, uint64_t n2, uint64_t n3, uint64_t n4) {   // :3-15
+        s[0] = n1; s[1] = n2; s[2] = n3; s[3] = n4;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) S[i][j] = xe_next();
+    }
+    __device__ __forceinline__ void regen_pool() {                          // :35-69
+        for (int j = 0; j < 4; j++) {
+            const uint64_t r = S[0][j] + S[1][j];
+            pool[2 * j] = u2f(((uint32_t)r & 0x007fffffu) | 0x3f800000u) - 1.0f;
+            pool[2 * j + 1] = u2f(((uint32_t)(r >> 32) & 0x007fffffu) | 0x3f800000u) - 1.0f;
+            const uint64_t t = S[1][j] << 17;
+            S[2][j] ^= S[0][j]; S[3][j] ^= S[1][j]; S[1][j] ^= S[2][j]; S[0][j] ^= S[3][j];
+            S[2][j] ^= t;
+            S[3][j] = rotl(S[3][j], 45);
+        }
+    }
+    __device__ __forceinline__ float fRand(float lo, float hi) {            // :119-132
+        const float f = (float)((double)(xe_next() >> 11) * 0x1.0p-53);
+        return lo + f * (hi - lo);
+    }
+};

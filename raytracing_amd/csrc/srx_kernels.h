@@ -69,3 +69,7 @@ extern "C" hipError_t srx_launch_pack_rays(const float* org3, const float* dir3,
                                            GRay* rays, hipStream_t stream);
 extern "C" hipError_t srx_launch_accumulate(int res_x, int x0, int w, GRows rows_map, int rows, uint32_t pass_index, int n_passes,
                                             uint32_t slot_stride, float* sample3, float* accum4, float* aux4, hipStream_t stream);
+// the reference's own generator on the device (XorRandom.cpp): primaries of a rectangle from ONE sequential XorGen stream, and raw streams
+extern "C" hipError_t srx_launch_raygen_xorgen(const GCamera& c, int x0, int y0, int w, int h, uint32_t pass_index, const uint64_t* seed4, float* dir3,
+                                               hipStream_t stream);
+extern "C" hipError_t srx_launch_xorgen_stream(const uint64_t* seed4, uint32_t n_pools, uint32_t n_scalar, float* pools8, float* scalars, hipStream_t stream);

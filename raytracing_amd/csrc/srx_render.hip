@@ -423,3 +423,41 @@ extern "C" int srx_camera_rays(const srx_camera* camera, int32_t x0, int32_t y0,
     if (e != hipSuccess) SRX_FAIL(std::string("srx_camera_rays: ") + hipGetErrorString(e));
     return 0;
 }
+
+// Camera::random_slope_at (Camera.h:91-97, :138-140) with the reference's own generator: ONE XorGen (XorRandom.cpp) seeded
+// with seed4, two fRand draws per pixel, pixels in row-major order of the rectangle. The parity ray sets of SURVEY 8(d).
+extern "C" int srx_camera_rays_xorgen(const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h, uint32_t pass_index,
+                                      const uint64_t* seed4, float* dir3) {
+    if (!camera || !seed4 || !dir3) SRX_FAIL("srx_camera_rays_xorgen: null argument");
+    if (camera->res_x <= 0 || camera->res_y <= 0 || camera->subdiv <= 0) SRX_FAIL("srx_camera_rays_xorgen: bad camera");
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > camera->res_x || y0 + h > camera->res_y)
+        SRX_FAIL("srx_camera_rays_xorgen: rectangle outside the camera resolution");
+    if ((uint64_t)w * h > (1u << 22)) SRX_FAIL("srx_camera_rays_xorgen: at most 2^22 rays (one sequential generator stream)");
+    GCamera cam;
+    std::memcpy(&cam, camera, sizeof(cam));
+    const size_t n = (size_t)w * h;
+    float* d_d = nullptr;
+    SRX_HIP(hipMalloc((void**)&d_d, n * 12));
+    hipError_t e = srx_launch_raygen_xorgen(cam, x0, y0, w, h, pass_index, seed4, d_d, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(dir3, d_d, n * 12, hipMemcpyDeviceToHost);
+    (void)hipFree(d_d);
+    if (e != hipSuccess) SRX_FAIL(std::string("srx_camera_rays_xorgen: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// XorGen streams from the device (XorRandom.cpp:35-69 pools, :119-132 scalars), pools first: for parity tests of the generator itself.
+extern "C" int srx_xorgen_stream(const uint64_t* seed4, uint32_t n_pools, uint32_t n_scalar, float* pools8, float* scalars) {
+    if (!seed4 || (n_pools && !pools8) || (n_scalar && !scalars)) SRX_FAIL("srx_xorgen_stream: null argument");
+    if ((uint64_t)n_pools + n_scalar > (1u << 22)) SRX_FAIL("srx_xorgen_stream: at most 2^22 draws");
+    float *d_p = nullptr, *d_s = nullptr;
+    hipError_t e = hipMalloc((void**)&d_p, std::max<size_t>(1, (size_t)n_pools * 32));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_s, std::max<size_t>(1, (size_t)n_scalar * 4));
+    if (e == hipSuccess) e = srx_launch_xorgen_stream(seed4, n_pools, n_scalar, d_p, d_s, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && n_pools) e = hipMemcpy(pools8, d_p, (size_t)n_pools * 32, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_scalar) e = hipMemcpy(scalars, d_s, (size_t)n_scalar * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_p); (void)hipFree(d_s);
+    if (e != hipSuccess) SRX_FAIL(std::string("srx_xorgen_stream: ") + hipGetErrorString(e));
+    return 0;
+}

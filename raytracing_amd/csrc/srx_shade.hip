@@ -417,7 +417,8 @@ __global__ __launch_bounds__(64 * SRX_SHADE_WAVES) void k_shade(GScene sc, Shade
 }
 
 // ---------------------------------------------------------------- primary rays (Camera.h:86-97,134-140)
-__device__ __forceinline__ f3 camera_slope(const GCamera& c, int px, int py, uint32_t pass_index, KeyedGen& g) {
+template <class Gen>
+__device__ __forceinline__ f3 camera_slope(const GCamera& c, int px, int py, uint32_t pass_index, Gen& g) {
     const float partial_width = c.lens_width / c.res_x;                // RectLens::_prep_function :50-85
     const float partial_height = c.lens_height / c.res_y;
     const float offset_x = -c.lens_width / 2;
@@ -463,6 +464,39 @@ __global__ __launch_bounds__(256) void k_raygen(GCamera c, int x0, int w, GRows 
     }
     if (dir3) { dir3[3 * (size_t)idx] = d.x; dir3[3 * (size_t)idx + 1] = d.y; dir3[3 * (size_t)idx + 2] = d.z; }
     if (keys) keys[idx] = g.s;
+}
+
+// ---- primary rays and raw streams from the reference's own generator (parity ray sets of fixed XorRandom seeds)
+// One sequential stream for the whole rectangle, two draws per pixel in row-major order: the thread of row r skips the
+// 2 w r draws of the rows above it first (a sequential generator; the sets are 65 536 rays, not frames).
+__global__ __launch_bounds__(64) void k_raygen_xorgen(GCamera c, int x0, int y0, int w, int h, uint32_t pass_index, uint64_t s0, uint64_t s1,
+                                                     uint64_t s2, uint64_t s3, float* dir3) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= h) return;
+    XorGen g;
+    g.seed(s0, s1, s2, s3);
+    for (long long k = 0; k < 2ll * w * row; k++) (void)g.xe_next();
+    for (int x = 0; x < w; x++) {
+        const f3 d = camera_slope(c, x0 + x, y0 + row, pass_index, g);
+        float* o = dir3 + 3 * ((size_t)row * w + x);
+        o[0] = d.x; o[1] = d.y; o[2] = d.z;
+    }
+}
+__global__ void k_xorgen_stream(uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3, uint32_t n_pools, uint32_t n_scalar, float* pools8, float* scalars) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    XorGen g;
+    g.seed(s0, s1, s2, s3);
+    for (uint32_t i = 0; i < n_pools; i++) { g.regen_pool(); for (int k = 0; k < 8; k++) pools8[8 * (size_t)i + k] = g.pool[k]; }
+    for (uint32_t i = 0; i < n_scalar; i++) scalars[i] = g.fRand(0.0f, 1.0f);
+}
+extern "C" hipError_t srx_launch_raygen_xorgen(const GCamera& c, int x0, int y0, int w, int h, uint32_t pass_index, const uint64_t* seed4, float* dir3,
+                                               hipStream_t stream) {
+    hipLaunchKernelGGL(k_raygen_xorgen, dim3((h + 63) / 64), dim3(64), 0, stream, c, x0, y0, w, h, pass_index, seed4[0], seed4[1], seed4[2], seed4[3], dir3);
+    return hipGetLastError();
+}
+extern "C" hipError_t srx_launch_xorgen_stream(const uint64_t* seed4, uint32_t n_pools, uint32_t n_scalar, float* pools8, float* scalars, hipStream_t stream) {
+    hipLaunchKernelGGL(k_xorgen_stream, dim3(1), dim3(64), 0, stream, seed4[0], seed4[1], seed4[2], seed4[3], n_pools, n_scalar, pools8, scalars);
+    return hipGetLastError();
 }
 
 // ---- adaptive visit (RenderThread::process_iteratively, SceneManager.h:193-237)

@@ -244,6 +244,27 @@ def camera_rays(camera, rect, pass_index, seed):
     return d, k
 
 
+def camera_rays_xorgen(camera, rect, pass_index, seed4=(1, 2, 3, 4)):
+    """`Camera::random_slope_at` with the reference's own `XorGen` (XorRandom.cpp), one sequential stream seeded with
+    `seed4`, two draws per pixel in row-major order: the parity ray sets of fixed XorRandom seeds."""
+    cam = np.ascontiguousarray(camera)
+    x0, y0, w, h = rect
+    d = np.zeros((w * h, 3), np.float32)
+    s4 = np.asarray(seed4, np.uint64)
+    check(_lib.lib().srx_camera_rays_xorgen(_p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w), C.c_int32(h),
+                                            C.c_uint32(pass_index), _p(s4), _p(d)), "srx_camera_rays_xorgen")
+    return d
+
+
+def xorgen_stream(seed4, n_pools, n_scalar):
+    """(pools[n_pools, 8], scalars[n_scalar]) of one `XorGen` seeded with seed4, computed on the device."""
+    s4 = np.asarray(seed4, np.uint64)
+    po = np.zeros((n_pools, 8), np.float32)
+    sc = np.zeros(n_scalar, np.float32)
+    check(_lib.lib().srx_xorgen_stream(_p(s4), C.c_uint32(n_pools), C.c_uint32(n_scalar), _p(po), _p(sc)), "srx_xorgen_stream")
+    return po, sc
+
+
 REGION_DTYPE = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("active", "<i4"), ("noise", "<f4"),
                          ("max_noise", "<f4"), ("min_noise", "<f4"), ("avg_noise", "<f4")])
 

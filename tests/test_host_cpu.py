@@ -38,6 +38,18 @@ def test_product_packager_matches_oracle_bytes(make):
     assert np.array_equal(n, PS.avx_bvh) and np.array_equal(pk, PS.avx_tri_data) and np.array_equal(tr, PS.tri_data)
 
 
+def test_counts_of_the_2000_triangle_soup():
+    """DESIGN.md section 2 cites them: the 2 000-triangle soup packages to 73 nodes and 250 packets in both
+    implementations — the counts SURVEY 8(c) recorded for a 2 000-triangle scene built by the reference itself (that
+    scene's triangles were not kept, so this pins a count, not bytes: 250 = every leaf full, 73 = the 8-wide collapse
+    of a median-split tree over 250 leaves)."""
+    desc = scenes.soup(2000, seed=3)
+    PS = engine.package(desc)
+    S = sro.OracleScene(desc, build_tables=False)
+    assert (len(PS.avx_bvh), len(PS.avx_tri_data), len(PS.tri_data)) == (73, 250, 2000)
+    assert S.counts() == (73, 250, 2000)
+
+
 def test_degenerate_inputs():
     """Ragged/edge inputs of the packager: one triangle, 9 coincident triangles (degenerate split, a leaf with
     more than 8 triangles -> 2 packets), and zero triangles (the reference asserts, BVH.h:100)."""
