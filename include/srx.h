@@ -213,6 +213,13 @@ typedef struct srx_noise_region {          /* SceneManager::noise_region, SceneM
 /* one region covering the frame (SceneManager.h:937-938); minimum_samples < 0 = the reference's 64 (:301) */
 int srx_noise_create(int32_t res_x, int32_t res_y, uint64_t seed, int32_t minimum_samples, srx_noise** out);
 void srx_noise_destroy(srx_noise* c);
+/* Options that leave the reference's behaviour (all off by default = the parity path).
+ * SRX_NOISE_ABS_LUMINANCE: the error term |L - L_aux| / max(L^1.1, L) (:568-572) takes |L| in the denominator. In the
+ * reference a pixel with negative luminance (direct light on a surface that faces away from the sun is negative,
+ * Core.h:461-463) makes pow(L, 1.1f) NaN, then its region's noise, then every block priority: sampling stops on any
+ * sunlit scene (quirk Q11). With the option on such pixels count like positive ones. */
+#define SRX_NOISE_ABS_LUMINANCE 1
+int srx_noise_set_option(srx_noise* c, int32_t option, int32_t value);
 /* device: d_err[pixel] = |L - L_aux| / max(L^1.1, L) (:568-572; 0 where L == 0) for the rows this caller owns
  * (interleave as in srx_trace_pass_interleaved) and 0 elsewhere, so a sum over the callers completes the map;
  * *min_samples = the smallest per-pixel sample count among the owned rows (:492-501). */

@@ -242,13 +242,14 @@ def poly_acos(x):
 
 
 # ---- adaptive-sampling controller (oracle/sro_noise.h) ------------------------------------------------------
-def noise_error_map(accum4, aux4):
-    """(err[npix], minimum sample count): SceneManager.h:566-572 per pixel, :492-501."""
+def noise_error_map(accum4, aux4, abs_luminance=False):
+    """(err[npix], minimum sample count): SceneManager.h:566-572 per pixel, :492-501. abs_luminance mirrors the product's
+    opt-in SRX_NOISE_ABS_LUMINANCE (not the reference)."""
     a = np.ascontiguousarray(accum4, np.float32).reshape(-1, 4)
     x = np.ascontiguousarray(aux4, np.float32).reshape(-1, 4)
     err = np.zeros(len(a), np.float32)
     mn = C.c_int32(0)
-    lib().sro_noise_error_map(_p(a), _p(x), C.c_uint64(len(a)), _p(err), C.byref(mn))
+    lib().sro_noise_error_map(_p(a), _p(x), C.c_uint64(len(a)), _p(err), C.byref(mn), C.c_int32(int(bool(abs_luminance))))
     return err, mn.value
 
 

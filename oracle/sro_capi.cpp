@@ -399,10 +399,10 @@ int sro_render_pass(void* hv, const sro_camera_in* c, int32_t x0, int32_t y0, in
 }
 
 // ---- adaptive-sampling controller (SceneManager.h:526-692) ------------------
-void sro_noise_error_map(const float* accum4, const float* aux4, uint64_t npix, float* err, int32_t* min_samples) {
+void sro_noise_error_map(const float* accum4, const float* aux4, uint64_t npix, float* err, int32_t* min_samples, int32_t abs_luminance) {
     int mn = npix ? (int)accum4[3] : 0;
     for (uint64_t i = 0; i < npix; i++) {
-        err[i] = noise_pixel_error(accum4 + 4 * i, aux4 + 4 * i);
+        err[i] = noise_pixel_error(accum4 + 4 * i, aux4 + 4 * i, abs_luminance != 0);
         mn = std::min(mn, (int)accum4[4 * i + 3]);
     }
     if (min_samples) *min_samples = mn;

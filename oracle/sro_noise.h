@@ -29,12 +29,14 @@ struct NoiseRegion {                       // SceneManager.h:262-273
 inline float noise_luminance(float r, float g, float b) { return r * 0.2126f + g * 0.7152f + b * 0.0722f; }
 
 // per-pixel term of SceneManager.h:568-572; 0 where the reference `continue`s (main luminance 0)
-inline float noise_pixel_error(const float* main4, const float* aux4) {
+// abs_luminance: the product's opt-in SRX_NOISE_ABS_LUMINANCE (NOT the reference): |L| in the denominator
+inline float noise_pixel_error(const float* main4, const float* aux4, bool abs_luminance = false) {
     const float main_lum = noise_luminance(main4[0], main4[1], main4[2]);
     const float aux_lum = noise_luminance(aux4[0], aux4[1], aux4[2]);
     const float delta = std::fabs(main_lum - aux_lum);
     if (main_lum == 0) return 0.0f;
-    return delta / std::max(std::pow(main_lum, 1.1f), main_lum);
+    const float den_lum = abs_luminance ? std::fabs(main_lum) : main_lum;
+    return delta / std::max(std::pow(den_lum, 1.1f), den_lum);
 }
 
 // keyed uniform in [lo, hi): one draw addressed by (seed, a, b), conversions of XorRandom.cpp:119-121

@@ -18,7 +18,7 @@ EXPORTS = [
     "srx_cast_closest", "srx_cast_closest_device", "srx_cast_closest_device_static", "srx_cast_shadow", "srx_cast_shadow_device",
     "srx_renderer_create", "srx_renderer_destroy", "srx_renderer_set_timing",
     "srx_trace_pass", "srx_trace_pass_interleaved", "srx_trace_passes_interleaved", "srx_trace_pass_adaptive", "srx_process_rays", "srx_camera_rays", "srx_camera_rays_xorgen", "srx_xorgen_stream",
-    "srx_noise_create", "srx_noise_destroy", "srx_noise_error_map", "srx_noise_analyze", "srx_noise_regions", "srx_noise_priorities",
+    "srx_noise_create", "srx_noise_destroy", "srx_noise_set_option", "srx_noise_error_map", "srx_noise_analyze", "srx_noise_regions", "srx_noise_priorities",
     "srx_buffer_create", "srx_buffer_destroy", "srx_buffer_read", "srx_buffer_clear", "srx_post_process", "srx_write_raw", "srx_read_raw", "srx_write_png",
     "srx_gltf_load", "srx_gltf_destroy", "srx_gltf_get",
 ]

@@ -26,7 +26,7 @@ __device__ __forceinline__ float lum3(float r, float g, float b) { return r * 0.
 
 // owned rows (GRows) get their error, the other rows 0, so an all-reduce(sum) over the GPUs completes the map
 __global__ __launch_bounds__(256) void k_noise_error(const float4* accum4, const float4* aux4, int res_x, int res_y, GRows rm, float* err,
-                                                    int* min_samples) {
+                                                    int* min_samples, int abs_luminance) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = (uint32_t)res_x * (uint32_t)res_y;
     int mine = 0x7fffffff;
@@ -39,7 +39,10 @@ __global__ __launch_bounds__(256) void k_noise_error(const float4* accum4, const
             const float4 m = accum4[idx], a = aux4[idx];
             const float main_lum = lum3(m.x, m.y, m.z), aux_lum = lum3(a.x, a.y, a.z);
             const float delta = fabsf(main_lum - aux_lum);
-            if (main_lum != 0.0f) e = delta / std_max(powf(main_lum, 1.1f), main_lum);   // :571-572
+            // :571-572. A negative main_lum makes powf NaN, the region's noise NaN and every priority NaN (quirk Q11);
+            // abs_luminance (opt-in, NOT the reference) takes |main_lum| in the denominator instead
+            const float den_lum = abs_luminance ? fabsf(main_lum) : main_lum;
+            if (main_lum != 0.0f) e = delta / std_max(powf(den_lum, 1.1f), den_lum);
             mine = (int)m.w;
         }
         err[idx] = e;
@@ -128,6 +131,7 @@ struct srx_noise {
     uint64_t seed = 0;
     uint32_t analyses = 0;
     int minimum_samples = 64;                     // SceneManager.h:301
+    int abs_luminance = 0;                        // SRX_NOISE_ABS_LUMINANCE (opt-in, not the reference)
     std::vector<srx_noise_region> regions;
     // device scratch, grown on demand
     RectJob* d_jobs = nullptr; size_t jobs_cap = 0;
@@ -220,6 +224,12 @@ extern "C" int srx_noise_create(int32_t res_x, int32_t res_y, uint64_t seed, int
     return 0;
 }
 
+extern "C" int srx_noise_set_option(srx_noise* c, int32_t option, int32_t value) {
+    if (!c) SRX_FAIL("srx_noise_set_option: null controller");
+    if (option == SRX_NOISE_ABS_LUMINANCE) { c->abs_luminance = value != 0; return 0; }
+    SRX_FAIL("srx_noise_set_option: unknown option");
+}
+
 extern "C" void srx_noise_destroy(srx_noise* c) {
     if (!c) return;
     (void)hipFree(c->d_jobs); (void)hipFree(c->d_cols); (void)hipFree(c->d_rows); (void)hipFree(c->d_col_totals);
@@ -237,7 +247,7 @@ extern "C" int srx_noise_error_map(srx_noise* c, const float* d_accum4, const fl
     SRX_HIP(hipMemcpy(c->d_min, &big, sizeof(int), hipMemcpyHostToDevice));
     const uint32_t n = (uint32_t)c->res_x * (uint32_t)c->res_y;
     hipLaunchKernelGGL(k_noise_error, dim3((n + 255) / 256), dim3(256), 0, 0, (const float4*)d_accum4, (const float4*)d_aux4, c->res_x,
-                       c->res_y, rm, d_err, c->d_min);
+                       c->res_y, rm, d_err, c->d_min, c->abs_luminance);
     SRX_HIP(hipGetLastError());
     int mn = 0;
     SRX_HIP(hipMemcpy(&mn, c->d_min, sizeof(int), hipMemcpyDeviceToHost));

@@ -275,13 +275,18 @@ class NoiseController:
 
     BLOCK = 4                                 # SceneManager.h:299
 
-    def __init__(self, res_x, res_y, seed=0, minimum_samples=-1, device=0):
+    ABS_LUMINANCE = 1                         # SRX_NOISE_ABS_LUMINANCE
+
+    def __init__(self, res_x, res_y, seed=0, minimum_samples=-1, device=0, abs_luminance=False):
         self.L = _lib.lib()
         check(self.L.srx_init(C.c_int(device)), "srx_init")
         self.res_x, self.res_y = int(res_x), int(res_y)
         self.h = C.c_void_p()
         check(self.L.srx_noise_create(C.c_int32(res_x), C.c_int32(res_y), C.c_uint64(seed), C.c_int32(minimum_samples),
                                       C.byref(self.h)), "srx_noise_create")
+        if abs_luminance:
+            # opt-in, not the reference: negative luminances do not turn the whole controller NaN (quirk Q11)
+            check(self.L.srx_noise_set_option(self.h, C.c_int32(self.ABS_LUMINANCE), C.c_int32(1)), "srx_noise_set_option")
 
     def close(self):
         if self.h:

@@ -1,0 +1,178 @@
+"""The two BASELINE.json configurations round 1 left without a GPU test.
+
+C4 (configs[3]): 10 M triangles at 3840x2160, 8 GPUs tile-sharded. Here: the 10 M-triangle atrium, package equality of
+the product's threaded builder and the oracle, every 97th 4K primary and its secondary ray against the oracle at 0 ulp
+with equal traversal counters, and one rank's 1/8 interleaved share of the 4K frame (two passes in one call) through
+size-independent properties plus an oracle crop.
+
+C3 (configs[2]): the textured interior (normal maps, transmission) WITH adaptive sampling on: the controller loop
+(error map -> analyze_noise -> priorities -> visits, SceneManager.h:970-993) on the interior scene in lockstep with the
+oracle's restatement.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_rays
+from test_cast_gpu import _assert_hits_equal
+from test_shade_gpu import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c4_ten_million_triangles_at_4k(tables):
+    import torch
+    from oracle import sro
+    from raytracing_amd import engine, scenes, tiles
+    desc = scenes.atrium(10_000_000, res=(3840, 2160), subdiv=4, max_generations=8, tex_size=64)
+    assert len(desc.tris) == 10_000_000
+    PS = engine.package(desc, tables=tables)
+    S = sro.OracleScene(desc, tables=tables)
+    on, op, ot = S.packaged()
+    assert np.array_equal(on, PS.avx_bvh) and np.array_equal(op, PS.avx_tri_data) and np.array_equal(ot, PS.tri_data)
+    del on, op, ot
+    RE = engine.RayEngine(0)
+    RE.load_scene(PS)
+    assert RE.stack_bound() > 52                                   # deeper than the LDS budget: the overflow form of the kernel runs
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    # ---- every 97th primary of the 4K frame and a secondary ray from its hit point
+    dirs, keys = sro.camera_rays_keyed(cam, (0, 0, w, h), 0, 20241111)
+    sel = np.arange(0, len(dirs), 97)
+    d1 = dirs[sel]
+    o1 = np.tile(np.asarray(cam["position"], np.float32), (len(d1), 1))
+    g, gc, adv = RE.execute_ray_cast(o1, d1, want_advanced=True)
+    c, cc, adv_c = S.cast_closest(o1, d1, want_advanced=True)
+    _assert_hits_equal(g, c)
+    assert np.array_equal(adv.view(np.uint32), adv_c.view(np.uint32))
+    assert int(gc[0]) == int(cc[0]) and int(gc[1]) == int(cc[1]) - int(cc[3]) and int(cc[4]) == 0
+    hit = g["material"] != 0xFFFFFFFF
+    assert hit.mean() > 0.9
+    _, d2 = random_rays(int(hit.sum()), seed=2)
+    g2, gc2 = RE.execute_ray_cast(adv[hit], d2)
+    c2, cc2 = S.cast_closest(adv[hit], d2)
+    _assert_hits_equal(g2, c2)
+    assert int(gc2[0]) == int(cc2[0]) and int(gc2[1]) == int(cc2[1]) - int(cc2[3]) and int(cc2[4]) == 0
+    # the whole frame's primaries in one launch (8.3 M rays: the 8-rays-per-octet overflow form) agree with the subset
+    o_all = np.tile(np.asarray(cam["position"], np.float32), (len(dirs), 1))
+    g_all, _ = RE.execute_ray_cast(o_all, dirs)
+    _assert_hits_equal(g_all[sel], c)
+    del o_all, g_all
+    # ---- rank 0's share of an 8-GPU run: every 8th tile row of the 4K frame, two passes in one call
+    share = (tiles.TILE, 0, 8)
+    acc = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+    aux = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctr = RE.trace_pass(cam, (0, 0, w, h), 0, 20241111, acc, aux, ray_capacity=1 << 26, interleave=share, n_passes=2)
+    torch.cuda.synchronize()
+    own = tiles.interleaved_rows(0, 8, h).numpy()
+    n_own = len(own) * w
+    assert int(ctr["rays_processed"]) == 2 * n_own + int(ctr["diffuses_cast"])
+    assert int(ctr["shadows_cast"]) == int(ctr["hits"]) * len(desc.suns)
+    assert 2 * 25 * n_own < int(ctr["rays_processed"]) < 2 * 40 * n_own
+    cnt = acc[:, 3].reshape(h, w)
+    mask = torch.zeros(h, dtype=torch.bool, device="cuda"); mask[torch.from_numpy(own).cuda()] = True
+    assert float(cnt[~mask].abs().max()) == 0.0 and float(acc[:, :3].reshape(h, w, 3)[~mask].abs().max()) == 0.0   # other ranks' rows untouched
+    assert float((cnt[mask] == 2).float().mean()) > 0.999 and float(aux[:, 3].max()) == 1.0
+    assert bool(torch.isfinite(acc).all()) and float(acc[:, :3].mean()) > 0
+    # a 48 x 8 crop of the owned rows by the oracle (same keyed samples)
+    y0 = int(own[len(own) // 2]) // tiles.TILE * tiles.TILE
+    x0, cw, ch = 1900, 48, tiles.TILE
+    assert all(y in set(own.tolist()) for y in range(y0, y0 + ch))
+    acc_c = np.zeros((h * w, 4), np.float32); aux_c = np.zeros((h * w, 4), np.float32)
+    for p in range(2):
+        S.render_pass(cam, (x0, y0, cw, ch), p, 20241111, acc_c, aux_c, mode=0, threads=8)
+    rows = (np.arange(y0, y0 + ch)[:, None] * w + np.arange(x0, x0 + cw)[None, :]).reshape(-1)
+    a = acc.cpu().numpy()
+    assert np.array_equal(a[rows, 3], acc_c[rows, 3])
+    _compare(a[rows, :3], acc_c[rows, :3])
+    RE.close()
+
+
+def _adaptive_loop(tables, abs_luminance):
+    """The mode-1 loop of SceneManager (SceneManager.h:970-993) on the interior, GPU and oracle in lockstep: unit-priority
+    visits until every pixel has minimum_samples, then rounds of error map -> analyze_noise -> balance -> visits. The
+    oracle's analysis takes the GPU's error map (the two maps differ by powf rounding only, checked every round), so
+    region lists, priorities and the blocks that fire must be identical."""
+    import torch
+    from oracle import sro
+    from raytracing_amd import engine, scenes
+    desc = scenes.interior(12000, res=(96, 54), subdiv=2, tex_size=64)
+    PS = engine.package(desc, tables=tables)
+    S = sro.OracleScene(desc, tables=tables)
+    RE = engine.RayEngine(0)
+    RE.load_scene(PS)
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    rect = (0, 0, w, h)
+    seed, min_samples = 31, 4
+    NC = engine.NoiseController(w, h, seed=seed, minimum_samples=min_samples, abs_luminance=abs_luminance)
+    ON = sro.OracleNoise(w, h, seed=seed, minimum_samples=min_samples)
+    acc = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda"); aux = torch.zeros_like(acc)
+    acc_c = np.zeros((h * w, 4), np.float32); aux_c = np.zeros((h * w, 4), np.float32)
+    d_err = torch.zeros(w * h, dtype=torch.float32, device="cuda")
+    d_pr = torch.ones(NC.n_blocks, dtype=torch.float32, device="cuda")
+    pr = np.ones(NC.n_blocks, np.float32)
+    visit = 0
+    log = []
+    for rnd in range(4):
+        for _ in range(min_samples if rnd == 0 else 2):
+            torch.cuda.synchronize()
+            RE.trace_visit(cam, rect, visit, seed, acc, aux, block_priority=d_pr)
+            S.render_pass_adaptive(cam, rect, visit, seed, acc_c, aux_c, block_priority=pr, threads=8)
+            visit += 1
+        torch.cuda.synchronize()
+        a, x = acc.cpu().numpy(), aux.cpu().numpy()
+        assert np.abs(a[:, 3] - acc_c[:, 3]).sum() <= 8           # the same blocks fired (non-finite rejects aside)
+        seen = NC.error_map(acc, aux, d_err)
+        err_g = d_err.cpu().numpy()
+        with np.errstate(all="ignore"):
+            err_c, seen_c = sro.noise_error_map(a, x, abs_luminance=abs_luminance)
+        assert seen == seen_c and np.array_equal(np.isnan(err_g), np.isnan(err_c))
+        assert np.allclose(err_g, err_c, rtol=4e-6, atol=0, equal_nan=True)
+        lum = a[:, 0] * 0.2126 + a[:, 1] * 0.7152 + a[:, 2] * 0.0722
+        NC.analyze_noise(d_err, seen)
+        ON.analyze(err_g, seen)
+        rg = NC.regions()
+        rc, sc = ON.regions()
+        assert np.array_equal(np.stack([rg["x0"], rg["y0"], rg["x1"], rg["y1"]], 1), rc)
+        assert np.array_equal(rg["active"], sc[:, 0].astype(np.int32))
+        assert np.allclose(rg["noise"], sc[:, 1], rtol=2e-6, atol=1e-12, equal_nan=True)
+        wrote = NC.balance(seen, d_pr)
+        pc, wrote_c = ON.priorities(seen)
+        assert wrote == wrote_c
+        pr = d_pr.cpu().numpy().copy()
+        assert np.allclose(pr, pc, rtol=1e-5, atol=1e-10, equal_nan=True)
+        log.append({"negative_pixels": int((lum < 0).sum()), "nan_errors": int(np.isnan(err_g).sum()), "regions": len(rg),
+                    "nan_regions": int(np.isnan(rg["noise"]).sum()), "nan_priorities": int(np.isnan(pr).sum()),
+                    "samples": float(a[:, 3].sum())})
+    cnt = acc[:, 3].cpu().numpy()
+    if not np.isnan(acc_c).any():
+        _compare(acc.cpu().numpy()[:, :3], acc_c[:, :3])
+        _compare(aux.cpu().numpy()[:, :3], aux_c[:, :3])
+    NC.close()
+    RE.close()
+    return log, cnt, pr, min_samples
+
+
+def test_c3_interior_adaptive_reference_behaviour(tables):
+    """Parity path. The interior is open towards the sun on the camera's side, so a few pixels see direct light on a
+    surface facing away from it: negative luminance (Core.h:461-463 has no clamp). pow(L, 1.1f) is NaN there, the
+    region's noise and then EVERY block priority become NaN (quirk Q11, SceneManager.h:571, :679-692), and a NaN
+    priority never fires (to_do = (int)NaN <= 0, :194-198): after the first analysis the reference stops sampling. GPU
+    and oracle do exactly that, NaN for NaN."""
+    log, cnt, pr, min_samples = _adaptive_loop(tables, abs_luminance=False)
+    assert log[0]["negative_pixels"] > 0 and log[0]["nan_errors"] == log[0]["negative_pixels"]
+    assert log[0]["nan_regions"] >= 1 and log[0]["nan_priorities"] == len(pr)
+    assert all(r["samples"] == log[0]["samples"] for r in log[1:])            # no visit fired anything after round 0
+    assert cnt.min() == cnt.max() == min_samples
+
+
+def test_c3_interior_adaptive_sampling_on(tables):
+    """C3 as BASELINE.json words it, adaptive sampling ON: with the opt-in SRX_NOISE_ABS_LUMINANCE (|L| in the error
+    term's denominator; not the reference, kept out of the parity path) the negative pixels no longer poison the
+    controller: priorities fall below 1 and blocks are skipped, identically on GPU and oracle."""
+    log, cnt, pr, min_samples = _adaptive_loop(tables, abs_luminance=True)
+    assert log[0]["negative_pixels"] > 0 and all(r["nan_errors"] == 0 and r["nan_priorities"] == 0 for r in log)
+    assert 0 < pr.mean() < 1 and (pr < 1).sum() > 0
+    assert cnt.min() >= min_samples and cnt.max() > cnt.min()                 # the controller really steers the sampling
+    assert log[-1]["samples"] > log[0]["samples"]
