@@ -94,6 +94,11 @@ class OracleScene:
         """Mirror of the product's SRX_LEAF_FILTER switch: off = count no packet test as saved."""
         self.L.sro_scene_set_leaf_filter(self.h, C.c_int32(int(bool(enabled))))
 
+    def set_simd(self, enabled):
+        """Casts through the AVX2-intrinsic node / packet tests (oracle/sro_trace_avx2.h): bit-identical results, no
+        leaf-filter bookkeeping; the timed CPU baseline of bench.py."""
+        self.L.sro_scene_set_simd(self.h, C.c_int32(int(bool(enabled))))
+
     def set_params(self, max_generations, monte_carlo_max, monte_carlo_modifier):
         self.L.sro_scene_set_params(self.h, C.c_int32(max_generations), C.c_int32(monte_carlo_max), C.c_float(monte_carlo_modifier))
 

@@ -96,6 +96,10 @@ int sro_scene_set_packaged(void* hv, const void* nodes, uint32_t n_nodes, const 
 // mirrors the product's SRX_LEAF_FILTER=0: with the filter off nothing is counted as saved
 void sro_scene_set_leaf_filter(void* hv, int32_t enabled) { ((Handle*)hv)->scene.geo.filter_enabled = enabled != 0; }
 
+// 1 = casts (and everything built on them) use the AVX2-intrinsic node and packet tests of sro_trace_avx2.h: same results
+// bit for bit, no leaf-filter bookkeeping in the counters; what bench.py times as the CPU baseline
+void sro_scene_set_simd(void* hv, int32_t enabled) { ((Handle*)hv)->scene.geo.simd = enabled != 0; }
+
 uint32_t sro_scene_counts(void* hv, uint32_t* n_nodes, uint32_t* n_packets, uint32_t* n_tris) {
     Handle* h = (Handle*)hv;
     *n_nodes = (uint32_t)h->scene.geo.avx_bvh.size();

@@ -295,6 +295,7 @@ struct PackagedGeometry {
     std::vector<PTri_AVX> avx_tri_data;
     std::vector<PackagedTri> tri_data;
     double build_seconds = 0;
+    bool simd = false;                     // casts through sro_trace_avx2.h (AVX2 intrinsics as the reference writes them) instead of the scalar loops
     // NOT part of the reference: the product's kernels skip a leaf whose padded tight box the ray misses (the
     // reference grows leaf boxes from the origin, quirk Q1, so most leaf visits cannot hit anything). The oracle
     // keeps the reference's traversal and only COUNTS the packet tests such a filter would save, with the same

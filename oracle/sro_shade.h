@@ -8,6 +8,7 @@
 // PARITY UNPINNED (no upstream tests; see sro_math.h header and DESIGN.md).
 #pragma once
 #include "sro_trace.h"
+#include "sro_trace_avx2.h"
 
 namespace sro {
 

@@ -203,11 +203,15 @@ static inline void iterativeBVH_AVX(const PackagedGeometry& data, CastResults& r
     if (ctr && maxdepth > ctr->max_stack) ctr->max_stack = maxdepth;
 }
 
+// sro_trace_avx2.h: the same cast with 8-wide AVX2 intrinsics (bit-identical; the timed CPU baseline)
+static inline void iterativeBVH_AVX2(const PackagedGeometry& data, CastResults& res, const XYZ& position, const XYZ& slope, TraceCounters* ctr);
+
 // Core.h:323-329,346-350 — origin is advanced in place, even on a miss.
 static inline CastResults execute_ray_cast(const PackagedGeometry& data, XYZ& position, const XYZ& slope,
                                            TraceCounters* ctr = nullptr) {
     CastResults r;
-    iterativeBVH_AVX(data, r, position, slope, ctr);
+    if (data.simd) iterativeBVH_AVX2(data, r, position, slope, ctr);
+    else iterativeBVH_AVX(data, r, position, slope, ctr);
     position += r.distance * slope * 0.999f;
     return r;
 }

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Derives the figures of profiles/r01_pmc_summary.md from a pmc_summary.py text file and a kernel_stats.csv.
-Usage: pmc_derive.py <pmc_summary.txt> <kernel_stats_single_stream.csv> <passes in the stats run>"""
+"""Derives the per-kernel figures of profiles/rNN_pmc_summary.md and the per-ray figures bench.py reads
+(profiles/rNN_pmc_derived.json) from a pmc_summary.py text file (counters of ONE 1-spp pass), a kernel_stats.csv and
+the bench line of the same workload.
+Usage: pmc_derive.py <pmc_raw.txt> <kernel_stats_single_stream.csv> <passes in the stats run> <bench.json>"""
 import csv, json, re, sys
 from collections import defaultdict
 
@@ -14,7 +16,14 @@ ms = defaultdict(float)
 for r in csv.DictReader(open(sys.argv[2])):
     k = re.sub(r"<(\d), \d(?:, \w+)?>", r"<\1>", r["Name"].split("(")[0].replace("void ", ""))
     ms[k] += float(r["TotalDurationNs"]) / 1e6 / int(sys.argv[3])
+bench = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
 out = {}
+if bench:
+    import re as _re
+    m = _re.search(r"(\d+) tris, (\d+x\d+)", bench["config"]["workload"])
+    out["workload"] = {"tris": int(m.group(1)), "res": m.group(2), "max_generations": 8}
+    out["rays_per_pass"] = bench["config"]["rays_per_step"]
+    out["shadow_rays_per_pass"] = bench["config"]["shadow_rays_per_step"]
 for k in ("k_trace<0>", "k_trace<2>", "k_shade"):
     g = lambda c: tot[(k, c)]
     t = ms[k]; cyc = t * 1e-3 * 2.4e9
@@ -29,5 +38,13 @@ for k in ("k_trace<0>", "k_trace<2>", "k_shade"):
          "ta_busy": g("TA_TA_BUSY_sum") / 256 / cyc, "td_busy": g("TD_TD_BUSY_sum") / 256 / cyc,
          "td_tc_stall_of_busy": g("TD_TC_STALL_sum") / max(1, g("TD_TD_BUSY_sum")),
          "lds_bank_conflict": g("SQ_LDS_BANK_CONFLICT") / max(1, g("SQ_LDS_IDX_ACTIVE"))}
+    d["write_GB"] = g("WRITE_SIZE") * 1000 / 1e9
+    if bench:
+        n = out["shadow_rays_per_pass"] if k == "k_trace<2>" else out["rays_per_pass"]
+        # memory-side bytes: FETCH_SIZE is KB and counts 128-B requests at 64 B on gfx950 (x2); WRITE_SIZE is KB
+        d["hbm_bytes_per_ray"] = (g("FETCH_SIZE") * 1000 * 2 + g("WRITE_SIZE") * 1000) / n
+        d["l2_request_bytes_per_ray"] = g("TCP_TCC_READ_REQ_sum") * 128 / n
+        d["l1_access_bytes_per_ray"] = g("TCP_TOTAL_CACHE_ACCESSES_sum") * 128 / n
+        d["valu_per_ray"] = g("SQ_INSTS_VALU") / n
     out[k] = d
 print(json.dumps(out, indent=1))
