@@ -220,7 +220,9 @@ struct Huff {
         fail("PNG: bad Huffman code");
     }
 };
-std::vector<uint8_t> inflate_zlib(const uint8_t* d, size_t n) {
+// max_out: what the caller can use (an image's (stride + 1) x height); a stream that inflates to more is refused, so a
+// small file cannot exhaust memory
+std::vector<uint8_t> inflate_zlib(const uint8_t* d, size_t n, size_t max_out) {
     if (n < 6) fail("PNG: zlib stream too short");
     BitReader br{d + 2, n - 2};
     std::vector<uint8_t> out;
@@ -237,6 +239,7 @@ std::vector<uint8_t> inflate_zlib(const uint8_t* d, size_t n) {
             const uint32_t len = br.d[br.pos] | (br.d[br.pos + 1] << 8);
             br.pos += 4;
             if (br.pos + len > br.n) fail("PNG: stored block cut off");
+            if (out.size() + len > max_out) fail("PNG: the compressed stream holds more data than the image needs");
             out.insert(out.end(), br.d + br.pos, br.d + br.pos + len);
             br.pos += len;
             continue;
@@ -276,7 +279,7 @@ std::vector<uint8_t> inflate_zlib(const uint8_t* d, size_t n) {
         }
         for (;;) {
             const int sym = lit.decode(br);
-            if (sym < 256) out.push_back((uint8_t)sym);
+            if (sym < 256) { if (out.size() >= max_out) fail("PNG: the compressed stream holds more data than the image needs"); out.push_back((uint8_t)sym); }
             else if (sym == 256) break;
             else {
                 if (sym > 285) fail("PNG: bad length symbol");
@@ -285,6 +288,7 @@ std::vector<uint8_t> inflate_zlib(const uint8_t* d, size_t n) {
                 if (ds > 29) fail("PNG: bad distance symbol");
                 const size_t dd = dbase[ds] + br.bits(dext[ds]);
                 if (dd > out.size()) fail("PNG: distance beyond the start");
+                if (out.size() + (size_t)len > max_out) fail("PNG: the compressed stream holds more data than the image needs");
                 for (int k = 0; k < len; k++) out.push_back(out[out.size() - dd]);
             }
         }
@@ -318,7 +322,8 @@ Image decode_png(const uint8_t* d, size_t n) {
     if (im.w <= 0 || im.h <= 0 || ctype < 0) fail("PNG: no IHDR");
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
     const size_t stride = (size_t)im.w * ch;
-    std::vector<uint8_t> raw = inflate_zlib(z.data(), z.size());
+    if ((uint64_t)im.w * (uint64_t)im.h > (1ull << 28)) fail("PNG: image larger than 2^28 pixels");
+    std::vector<uint8_t> raw = inflate_zlib(z.data(), z.size(), (stride + 1) * (size_t)im.h);
     if (raw.size() < (stride + 1) * (size_t)im.h) fail("PNG: pixel data too short");
     std::vector<uint8_t> img(stride * im.h);
     for (int y = 0; y < im.h; y++) {
@@ -422,6 +427,13 @@ struct Loader {
     std::vector<uint8_t> bin;
     srx_gltf* out;
 
+    // A JSON number that is to be a byte offset / length / count: finite, integral, >= 0 and no larger than `limit`.
+    // (A crafted file can hold -8 or 2^61 here; casting those to size_t and adding them wraps past a plain range check.)
+    static size_t to_size(double v, size_t limit, const char* what) {
+        if (!(v >= 0.0) || v != std::floor(v) || v > (double)limit) fail(std::string("glTF: ") + what + " is negative, fractional or beyond the file");
+        return (size_t)v;
+    }
+
     // ---- accessors (FileLoading.h:231-347)
     struct View { const uint8_t* p; size_t stride; size_t count; int comp_type; int ncomp; };
     View view(int accessor, int want_comp_type_a, int want_comp_type_b, int want_ncomp) {
@@ -436,10 +448,16 @@ struct Loader {
         if (bv.t != JV::OBJ) fail("glTF: accessor without a bufferView");
         if (bv.integer("buffer", 0) != 0) fail("glTF: only the binary chunk of the .glb is supported as a buffer");
         const size_t csz = (ct == 5123) ? 2 : 4;
-        const size_t off = (size_t)bv.number("byteOffset", 0) + (size_t)acc.number("byteOffset", 0);
-        const size_t stride = bv.has("byteStride") ? (size_t)bv.number("byteStride", 0) : csz * nc;
-        const size_t count = (size_t)acc.number("count", 0);
-        if (count && off + stride * (count - 1) + csz * nc > bin.size()) fail("glTF: accessor reaches beyond the binary chunk");
+        const size_t elem = csz * nc;
+        const size_t off = to_size(bv.number("byteOffset", 0), bin.size(), "bufferView byteOffset") +
+                           to_size(acc.number("byteOffset", 0), bin.size(), "accessor byteOffset");      // each <= bin.size(): no wrap
+        const size_t stride = bv.has("byteStride") ? to_size(bv.number("byteStride", 0), bin.size(), "byteStride") : elem;
+        const size_t count = to_size(acc.number("count", 0), bin.size(), "accessor count");              // an element has at least a byte
+        // off + stride * (count - 1) + elem <= bin.size(), written so that nothing can overflow
+        if (count) {
+            if (off > bin.size() || elem > bin.size() - off) fail("glTF: accessor reaches beyond the binary chunk");
+            if (count > 1 && (stride == 0 ? false : (count - 1) > (bin.size() - off - elem) / stride)) fail("glTF: accessor reaches beyond the binary chunk");
+        }
         return {bin.data() + off, stride, count, ct, nc};
     }
     std::vector<V3> vec3(int accessor) {
@@ -478,8 +496,9 @@ struct Loader {
         if (!im.has("bufferView")) fail("glTF: image \"" + im.str("name") + "\" is not embedded in the .glb (uri images are not read)");
         const JV& bv = root.get("bufferViews") ? root.get("bufferViews")->at((size_t)im.integer("bufferView", -1)) : JV();
         if (bv.t != JV::OBJ) fail("glTF: image bufferView out of range");
-        const size_t off = (size_t)bv.number("byteOffset", 0), len = (size_t)bv.number("byteLength", 0);
-        if (off + len > bin.size()) fail("glTF: image reaches beyond the binary chunk");
+        const size_t off = to_size(bv.number("byteOffset", 0), bin.size(), "image byteOffset");
+        const size_t len = to_size(bv.number("byteLength", 0), bin.size(), "image byteLength");
+        if (len > bin.size() - off) fail("glTF: image reaches beyond the binary chunk");
         const Image img = decode_png(bin.data() + off, len);
         base.push_back(load_texture(img, conv, with_scale, scale_v));
         return tex_cache[key] = (int)base.size() - 1;

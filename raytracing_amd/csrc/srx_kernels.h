@@ -6,6 +6,8 @@ struct TraceArgs {
     const float* org;  int org_stride;     // floats between consecutive ray origins
     const float* dir;  int dir_stride;     // unused by the shadow-queue form
     uint32_t n;
+    const uint32_t* n_ptr;                 // optional (device): the launch processes min(*n_ptr, n) rays; n sizes the grid (launches
+                                           // enqueued before the host knows how many rays the previous kernel produced)
     GHit* hits;                            // closest form
     float* advanced_org3;                  // optional: o + t*d*0.999f (Core.h:327)
     uint8_t* lit;                          // shadow form, API
@@ -31,6 +33,7 @@ struct ShadeArgs {
     const GRay* rays;              // queue segment being shaded
     const GHit* hits;              // hit record of each ray of the segment
     uint32_t n;
+    const uint32_t* n_ptr;         // optional (device): min(*n_ptr, n) rays, as in TraceArgs
     int generation;                // PackagedRay::generation of every ray in the segment (Ray.h:10)
     GRay* out_rays;                // next generation's rays are appended here ...
     uint32_t* out_count;           // ... at *out_count (device counter, one atomic per wave)

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#define SRX_RING 40           // chain mode: generations in flight without a host round trip (max_generations < 32)
 #define SRX_COUNT_PAD 512     // dwords between the two queue counters (2 KB: measured, shade kernel 41.2 -> 40.2 ms per 4 passes)
 namespace {
 
@@ -39,19 +40,29 @@ struct srx_renderer {
     GShadow* shadow_q[2] = {nullptr, nullptr};
     hipStream_t shadow_stream = nullptr;
     hipEvent_t shadow_done[2] = {nullptr, nullptr};     // recorded on shadow_stream after the kernel that reads queue i
-    hipEvent_t shadow_t0[2] = {nullptr, nullptr};       // timing: start of that kernel
     bool shadow_busy[2] = {false, false};               // an un-joined shadow kernel uses queue i
-    bool shadow_timed[2] = {false, false};
     int shadow_flip = 0;
     bool overlap_shadow = true;
+    // Chain mode (process_chain): generations whose fan-out is 1 are enqueued back to back, each kernel reading its ray
+    // count from the counters of the one before (no host round trip per generation); the counts come back through a
+    // pinned ring, one slot and one event per generation.
+    bool chain = true;
+    DeviceCounts* d_ring = nullptr;
+    DeviceCounts* h_ring = nullptr;
+    hipEvent_t ring_ev[SRX_RING];
+    // kernel timing (set_timing): event pairs from a pool, resolved when the call ends
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Timed { int kind; size_t e0, e1; };
+    std::vector<Timed> timed;
     DeviceCounts* d_counts = nullptr; // [3]: one per shadow queue, [2] for ray generation
     unsigned long long* d_counters = nullptr;
     float* sample3 = nullptr;         // per-pixel sample sums
     uint64_t sample_pixels = 0;
+    bool sample_dirty = false;        // a call ended half way: its sums are still in sample3
     hipStream_t stream = nullptr;
     DeviceCounts* h_counts = nullptr; // pinned
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // per-call accumulators
     uint64_t top = 0;
     srx_counters acc;
@@ -75,15 +86,18 @@ extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_
     chk(hipMalloc((void**)&r->hits, ray_capacity * sizeof(GHit)));
     if (const char* e2 = getenv("SRX_SHADOW_STREAM")) r->overlap_shadow = atoi(e2) != 0;   // experiments: 0 = one stream
     chk(hipStreamCreateWithFlags(&r->shadow_stream, hipStreamNonBlocking));
+    if (const char* e3 = getenv("SRX_CHAIN")) r->chain = atoi(e3) != 0;                    // experiments / tests: 0 = a host round trip per generation
     for (int i = 0; i < 2; i++) {
         chk(hipMalloc((void**)&r->shadow_q[i], r->shadow_capacity * sizeof(GShadow)));
-        chk(hipEventCreate(&r->shadow_done[i]));
-        chk(hipEventCreate(&r->shadow_t0[i]));
+        chk(hipEventCreateWithFlags(&r->shadow_done[i], hipEventDisableTiming));
     }
+    for (int i = 0; i < SRX_RING; i++) r->ring_ev[i] = nullptr;
+    for (int i = 0; i < SRX_RING; i++) chk(hipEventCreateWithFlags(&r->ring_ev[i], hipEventDisableTiming));
+    chk(hipMalloc((void**)&r->d_ring, SRX_RING * sizeof(DeviceCounts)));
+    chk(hipHostMalloc((void**)&r->h_ring, SRX_RING * sizeof(DeviceCounts)));
     chk(hipMalloc((void**)&r->d_counts, 3 * sizeof(DeviceCounts)));
     chk(hipMalloc((void**)&r->d_counters, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long)));
     chk(hipHostMalloc((void**)&r->h_counts, sizeof(DeviceCounts)));
-    for (int i = 0; i < 4; i++) chk(hipEventCreate(&r->ev[i]));
     if (e != hipSuccess) {
         srx_set_error(std::string("srx_renderer_create: ") + hipGetErrorString(e));
         srx_renderer_destroy(r);
@@ -101,12 +115,14 @@ extern "C" void srx_renderer_destroy(srx_renderer* r) {
     for (int i = 0; i < 2; i++) {
         (void)hipFree(r->shadow_q[i]);
         if (r->shadow_done[i]) (void)hipEventDestroy(r->shadow_done[i]);
-        if (r->shadow_t0[i]) (void)hipEventDestroy(r->shadow_t0[i]);
     }
+    for (int i = 0; i < SRX_RING; i++) if (r->ring_ev[i]) (void)hipEventDestroy(r->ring_ev[i]);
+    for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
+    (void)hipFree(r->d_ring);
+    if (r->h_ring) (void)hipHostFree(r->h_ring);
     if (r->shadow_stream) (void)hipStreamDestroy(r->shadow_stream);
     (void)hipFree(r->d_counts); (void)hipFree(r->d_counters); (void)hipFree(r->sample3);
     if (r->h_counts) (void)hipHostFree(r->h_counts);
-    for (int i = 0; i < 4; i++) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -128,18 +144,41 @@ int ensure_sample_buffer(srx_renderer* r, uint64_t pixels) {
     return 0;
 }
 
+// ---- kernel timing: an event pair per timed kernel, taken from a pool and read when the call ends (nothing waits on
+// the host for a time while work is being enqueued)
+enum { T_TRACE = 0, T_SHADE = 1, T_SHADOW = 2 };
+int t_begin(srx_renderer* r, int kind, hipStream_t st, size_t* slot) {
+    *slot = (size_t)-1;
+    if (!r->timing) return 0;
+    while (r->ev_used + 2 > r->ev_pool.size()) { hipEvent_t e; SRX_HIP(hipEventCreate(&e)); r->ev_pool.push_back(e); }
+    srx_renderer::Timed t{kind, r->ev_used, r->ev_used + 1};
+    r->ev_used += 2;
+    SRX_HIP(hipEventRecord(r->ev_pool[t.e0], st));
+    r->timed.push_back(t);
+    *slot = r->timed.size() - 1;
+    return 0;
+}
+int t_end(srx_renderer* r, size_t slot, hipStream_t st) {
+    if (slot == (size_t)-1) return 0;
+    SRX_HIP(hipEventRecord(r->ev_pool[r->timed[slot].e1], st));
+    return 0;
+}
+int resolve_timing(srx_renderer* r) {       // both streams have been waited for
+    for (const srx_renderer::Timed& t : r->timed) {
+        float ms = 0;
+        SRX_HIP(hipEventElapsedTime(&ms, r->ev_pool[t.e0], r->ev_pool[t.e1]));
+        if (t.kind == T_TRACE) r->acc.trace_ms += ms; else if (t.kind == T_SHADE) r->acc.shade_ms += ms; else r->acc.shadow_ms += ms;
+    }
+    r->timed.clear(); r->ev_used = 0;
+    return 0;
+}
+
 // The shadow kernel that read queue i has to be over before the queue is written again / before the sample buffer is
-// read: the main stream waits for it on the device (no host wait), and its time is taken once it is known to be over.
+// read: either the host waits for it, or the main stream does on the device.
 int retire_shadow(srx_renderer* r, int i, bool host_wait) {
     if (!r->shadow_busy[i]) return 0;
     if (host_wait) {
         SRX_HIP(hipEventSynchronize(r->shadow_done[i]));
-        if (r->shadow_timed[i]) {
-            float ms = 0;
-            SRX_HIP(hipEventElapsedTime(&ms, r->shadow_t0[i], r->shadow_done[i]));
-            r->acc.shadow_ms += ms;
-            r->shadow_timed[i] = false;
-        }
         r->shadow_busy[i] = false;
     } else {
         SRX_HIP(hipStreamWaitEvent(r->stream, r->shadow_done[i], 0));
@@ -153,11 +192,114 @@ int join_shadows(srx_renderer* r) {
     return 0;
 }
 
+// One batch of rays through the closest-hit kernel, the shade kernel and (on the second stream) the shadow kernel.
+// n_ptr (device, optional): the batch holds min(*n_ptr, n) rays, n only sizes the grids. The children go to `out`, their
+// number and the number of shadow rays to `dc` (device). q = the shadow queue the shade kernel fills.
+int launch_batch(srx_renderer* r, int gen, const GRay* in, uint32_t n, const uint32_t* n_ptr, GRay* out, DeviceCounts* dc, int q,
+                 bool shadow_count_on_device, uint32_t n_shadow_known, hipEvent_t shade_done) {
+    const GScene& g = r->scene->g;
+    size_t ts;
+    TraceArgs t;
+    std::memset(&t, 0, sizeof(t));
+    t.org = &in->ox; t.org_stride = sizeof(GRay) / 4;
+    t.dir = &in->dx; t.dir_stride = sizeof(GRay) / 4;
+    t.n = n; t.n_ptr = n_ptr;
+    t.hits = r->hits;
+    t.counters = r->d_counters + CTR_NODES; t.counter_slot_mask = CTR_SLOTS - 1; t.counter_slot_stride = CTR_COUNT;
+    if (t_begin(r, T_TRACE, r->stream, &ts)) return 1;
+    SRX_HIP(srx_launch_trace(0, g, t, r->stream));
+    if (t_end(r, ts, r->stream)) return 1;
+
+    ShadeArgs s;
+    std::memset(&s, 0, sizeof(s));
+    s.rays = in; s.hits = r->hits; s.n = n; s.n_ptr = n_ptr; s.generation = gen;
+    s.out_rays = out; s.out_count = &dc->out_count;
+    s.shadow_q = r->shadow_q[q]; s.shadow_count = &dc->shadow_count;
+    s.sample3 = r->sample3; s.counters = r->d_counters; s.counter_slot_mask = CTR_SLOTS - 1; s.counter_slot_stride = CTR_COUNT;
+    if (t_begin(r, T_SHADE, r->stream, &ts)) return 1;
+    SRX_HIP(srx_launch_shade(g, s, r->stream));
+    if (t_end(r, ts, r->stream)) return 1;
+    r->acc.trace_launches++; r->acc.shade_launches++;
+    if (!shadow_count_on_device) return 0;          // the caller launches the shadow kernel once it has the count
+    (void)n_shadow_known;
+    if (g.n_suns) {
+        // shadow rays of this batch, counted on the device: grid for the most there can be
+        SRX_HIP(hipEventRecord(shade_done, r->stream));
+        hipStream_t ss = r->overlap_shadow ? r->shadow_stream : r->stream;
+        if (ss != r->stream) SRX_HIP(hipStreamWaitEvent(ss, shade_done, 0));
+        TraceArgs sh;
+        std::memset(&sh, 0, sizeof(sh));
+        sh.org = &r->shadow_q[q][0].ox; sh.org_stride = sizeof(GShadow) / 4;
+        sh.n = n * g.n_suns; sh.n_ptr = &dc->shadow_count;
+        sh.shadow_q = r->shadow_q[q]; sh.sample3 = r->sample3;
+        sh.counters = r->d_counters + CTR_SNODES; sh.counter_slot_mask = CTR_SLOTS - 1; sh.counter_slot_stride = CTR_COUNT;
+        if (t_begin(r, T_SHADOW, ss, &ts)) return 1;
+        SRX_HIP(srx_launch_trace(2, g, sh, ss));
+        if (t_end(r, ts, ss)) return 1;
+        SRX_HIP(hipEventRecord(r->shadow_done[q], ss));
+        r->shadow_busy[q] = true;
+        r->shadow_flip ^= 1;
+        r->acc.shadow_launches++;
+    }
+    return 0;
+}
+
+// Chain mode: the batch [begin, begin + n) of generation `gen` and ALL its descendants, for generations whose fan-out
+// is 1 (bounce_count <= 1: from the fourth generation on with the reference's 32 x 0.25^g, every generation of a pure
+// path tracer). A ray then has at most one child, so n slots hold any generation: the generations ping-pong between two
+// regions above the top and every kernel takes its ray count from the counters the previous shade kernel left on the
+// device. The device never waits for the host: the counts come back through a pinned ring, and the host, two links
+// ahead at most, uses them to tighten the grids of the links still to be enqueued and to end the chain once a generation is empty.
+int process_chain(srx_renderer* r, int gen, uint64_t begin, uint64_t n) {
+    const GScene& g = r->scene->g;
+    const int links = g.max_generations - gen + 1;
+    GRay* const region[2] = {r->rays + r->top, r->rays + r->top + n};
+    SRX_HIP(hipMemsetAsync(r->d_ring, 0, (size_t)links * sizeof(DeviceCounts), r->stream));
+    const GRay* in = r->rays + begin;
+    const uint32_t* n_ptr = nullptr;
+    uint32_t bound = (uint32_t)n;
+    int used = 0;
+    for (int k = 0; k < links; k++) {
+        const int q = r->shadow_flip;
+        if (retire_shadow(r, q, false)) return 1;            // the shadow kernel that read queue q: the main stream waits on the device
+        if (launch_batch(r, gen + k, in, bound, n_ptr, region[k & 1], r->d_ring + k, q, true, 0, r->ring_ev[k])) return 1;
+        SRX_HIP(hipMemcpyAsync(r->h_ring + k, r->d_ring + k, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
+        if (!g.n_suns) SRX_HIP(hipEventRecord(r->ring_ev[k], r->stream));
+        else { SRX_HIP(hipEventRecord(r->ring_ev[k], r->stream)); }
+        used = k + 1;
+        if (gen + k >= g.max_generations) break;              // Core.h:473: this generation queued nothing
+        // The host stays at most two links ahead of the device: before link k + 1 is enqueued it has the count of link
+        // k - 1 (whose kernels are over or nearly so, while link k keeps the device busy), which bounds the rays of
+        // every later link and ends the chain when it is 0.
+        if (k >= 1) {
+            SRX_HIP(hipEventSynchronize(r->ring_ev[k - 1]));
+            const uint32_t c = r->h_ring[k - 1].out_count;    // rays of link k; link k + 1 has no more
+            if (c == 0) break;
+            bound = std::min(bound, c);
+        }
+        in = region[k & 1];
+        n_ptr = &r->d_ring[k].out_count;
+    }
+    SRX_HIP(hipStreamSynchronize(r->stream));
+    uint64_t rays = n;
+    for (int k = 0; k < used; k++) {
+        const uint64_t c = r->h_ring[k].out_count, sh = r->h_ring[k].shadow_count;
+        if (c > n || sh > n * g.n_suns) SRX_FAIL("srx: internal error, a chained generation grew");
+        if (k + 1 < used) rays += c;
+        else if (c != 0 && gen + k < g.max_generations) SRX_FAIL("srx: internal error, a chain ended with rays left");
+        r->acc.shadows_cast += sh;
+    }
+    r->acc.rays_processed += rays;
+    return 0;
+}
+
 // Process the queue segment [begin, end) of generation `gen`; children go above r->top.
 int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
     const GScene& g = r->scene->g;
     const bool spawns = gen < g.max_generations;                        // Core.h:473
     const uint64_t fan = spawns ? (uint64_t)std::max(1, g.bounce_count[gen]) : 0;
+    bool chain_ok = r->chain && g.max_generations - gen + 1 <= SRX_RING;
+    for (int d = gen; d < g.max_generations && chain_ok; d++) chain_ok = g.bounce_count[d] <= 1;
     while (begin < end) {
         uint64_t n = end - begin;
         if (fan) {
@@ -171,32 +313,18 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         if (g.n_suns) n = std::min(n, r->shadow_capacity / g.n_suns);
         if (n == 0) SRX_FAIL("srx: shadow queue too small");
 
-        // ---- closest hit
-        TraceArgs t;
-        std::memset(&t, 0, sizeof(t));
-        t.org = &r->rays[begin].ox; t.org_stride = sizeof(GRay) / 4;
-        t.dir = &r->rays[begin].dx; t.dir_stride = sizeof(GRay) / 4;
-        t.n = (uint32_t)n;
-        t.hits = r->hits;
-        t.counters = r->d_counters + CTR_NODES; t.counter_slot_mask = CTR_SLOTS - 1; t.counter_slot_stride = CTR_COUNT;
-        if (r->timing) SRX_HIP(hipEventRecord(r->ev[0], r->stream));
-        SRX_HIP(srx_launch_trace(0, g, t, r->stream));
-        if (r->timing) SRX_HIP(hipEventRecord(r->ev[1], r->stream));
+        if (chain_ok && fan == 1 && r->top + 2 * n <= r->capacity) {
+            if (process_chain(r, gen, begin, n)) return 1;
+            begin += n;
+            continue;
+        }
 
-        // ---- shade + bounce (appends children at top, shadow rays into shadow queue q)
+        // ---- closest hit, shade + bounce (children appended at top, shadow rays into queue q), then the counts
         const int q = r->shadow_flip;
         if (retire_shadow(r, q, true)) return 1;       // the kernel that read queue q two batches ago (over long since)
         DeviceCounts* const dc = r->d_counts + q;
         SRX_HIP(hipMemsetAsync(dc, 0, sizeof(DeviceCounts), r->stream));
-        ShadeArgs s;
-        std::memset(&s, 0, sizeof(s));
-        s.rays = r->rays + begin; s.hits = r->hits; s.n = (uint32_t)n; s.generation = gen;
-        s.out_rays = r->rays + r->top; s.out_count = &dc->out_count;
-        s.shadow_q = r->shadow_q[q]; s.shadow_count = &dc->shadow_count;
-        s.sample3 = r->sample3; s.counters = r->d_counters; s.counter_slot_mask = CTR_SLOTS - 1; s.counter_slot_stride = CTR_COUNT;
-        if (r->timing) SRX_HIP(hipEventRecord(r->ev[2], r->stream));
-        SRX_HIP(srx_launch_shade(g, s, r->stream));
-        if (r->timing) SRX_HIP(hipEventRecord(r->ev[3], r->stream));
+        if (launch_batch(r, gen, r->rays + begin, (uint32_t)n, nullptr, r->rays + r->top, dc, q, false, 0, nullptr)) return 1;
         SRX_HIP(hipMemcpyAsync(r->h_counts, dc, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
         SRX_HIP(hipStreamSynchronize(r->stream));
         const uint64_t n_children = r->h_counts->out_count, n_shadow = r->h_counts->shadow_count;
@@ -205,9 +333,8 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
 
         // ---- shadow rays of this batch, on the second stream: the kernel runs next to the closest-hit kernel of the
         // next generation (launched below on the main stream). The shade kernel that filled the queue is over (host
-        // synchronised above). Lit rays add their contribution to the sample buffer. (Launching it before the
-        // synchronisation, with a grid for the most rays there can be and the count read on the device, measured
-        // slower: 1250 against 1263 Mrays/s.)
+        // synchronised above). Lit rays add their contribution to the sample buffer. (For these large batches, launching
+        // it before the synchronisation with the count read on the device measured slower: 1250 against 1263 Mrays/s.)
         if (n_shadow) {
             TraceArgs sh;
             std::memset(&sh, 0, sizeof(sh));
@@ -216,21 +343,17 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
             sh.shadow_q = r->shadow_q[q]; sh.sample3 = r->sample3;
             sh.counters = r->d_counters + CTR_SNODES; sh.counter_slot_mask = CTR_SLOTS - 1; sh.counter_slot_stride = CTR_COUNT;
             hipStream_t ss = r->overlap_shadow ? r->shadow_stream : r->stream;
-            if (r->timing) SRX_HIP(hipEventRecord(r->shadow_t0[q], ss));
+            size_t ts;
+            if (t_begin(r, T_SHADOW, ss, &ts)) return 1;
             SRX_HIP(srx_launch_trace(2, g, sh, ss));
+            if (t_end(r, ts, ss)) return 1;
             SRX_HIP(hipEventRecord(r->shadow_done[q], ss));
-            r->shadow_busy[q] = true; r->shadow_timed[q] = r->timing;
+            r->shadow_busy[q] = true;
             r->shadow_flip ^= 1;
+            r->acc.shadow_launches++;
         }
         r->acc.rays_processed += n;
         r->acc.shadows_cast += n_shadow;
-        r->acc.trace_launches++; r->acc.shade_launches++;
-        if (n_shadow) r->acc.shadow_launches++;
-        if (r->timing) {
-            float ms = 0;
-            SRX_HIP(hipEventElapsedTime(&ms, r->ev[0], r->ev[1])); r->acc.trace_ms += ms;
-            SRX_HIP(hipEventElapsedTime(&ms, r->ev[2], r->ev[3])); r->acc.shade_ms += ms;
-        }
         // ---- next generation, depth first
         if (n_children) {
             const uint64_t old_top = r->top;
@@ -246,6 +369,12 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
 int begin_call(srx_renderer* r) {
     for (int i = 0; i < 2; i++) if (retire_shadow(r, i, true)) return 1;   // left over from a call that failed half way
     std::memset(&r->acc, 0, sizeof(r->acc));
+    r->timed.clear(); r->ev_used = 0;
+    // everything a failed call may have left running is over now (both shadow queues retired above, and every error path
+    // of this file comes after a synchronisation of the main stream or leaves nothing enqueued on it that uses sample3)
+    SRX_HIP(hipStreamSynchronize(r->stream));
+    if (r->sample_dirty && r->sample3) SRX_HIP(hipMemsetAsync(r->sample3, 0, r->sample_pixels * 3 * sizeof(float), r->stream));
+    r->sample_dirty = true;           // until end_call
     SRX_HIP(hipMemsetAsync(r->d_counters, 0, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long), r->stream));
     return 0;
 }
@@ -257,6 +386,7 @@ int end_call(srx_renderer* r, srx_counters* out) {
     SRX_HIP(hipMemcpyAsync(all.data(), r->d_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
     SRX_HIP(hipStreamSynchronize(r->stream));
     for (int i = 0; i < 2; i++) if (retire_shadow(r, i, true)) return 1;
+    if (resolve_timing(r)) return 1;
     unsigned long long c[CTR_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int sl = 0; sl < CTR_SLOTS; sl++) for (int k = 0; k < CTR_COUNT; k++) c[k] += all[(size_t)sl * CTR_COUNT + k];
     r->acc.nodes = c[CTR_NODES]; r->acc.packets = c[CTR_PACKETS];
@@ -264,6 +394,7 @@ int end_call(srx_renderer* r, srx_counters* out) {
     r->acc.hits = c[CTR_HITS]; r->acc.texels = c[CTR_TEXELS]; r->acc.pdf_lookups = c[CTR_PDF];
     r->acc.diffuses_cast = c[CTR_CHILDREN];
     if (out) *out = r->acc;
+    r->sample_dirty = false;          // the accumulate kernels and srx_process_rays leave sample3 zeroed
     return srx_scene_check_spill(r->scene);
 }
 
@@ -286,8 +417,8 @@ extern "C" int srx_trace_passes_interleaved(srx_renderer* r, const srx_camera* c
     if (group_rows <= 0 || nparts <= 0 || part < 0 || part >= nparts) SRX_FAIL("srx_trace_pass_interleaved: bad row interleave (group_rows, part, nparts)");
     const uint64_t npix = (uint64_t)camera->res_x * camera->res_y;
     if (npix * (uint64_t)n_passes > 0x00FFFFFFull) SRX_FAIL("srx_trace_pass: more than 2^24-1 pixels x passes in flight is not supported");
-    if (ensure_sample_buffer(r, npix * (uint64_t)n_passes)) return 1;
     if (begin_call(r)) return 1;
+    if (ensure_sample_buffer(r, npix * (uint64_t)n_passes)) return 1;
     static_assert(sizeof(GCamera) == sizeof(srx_camera), "camera layout");
     GCamera cam;
     std::memcpy(&cam, camera, sizeof(cam));
@@ -328,8 +459,8 @@ extern "C" int srx_trace_pass_adaptive(srx_renderer* r, const srx_camera* camera
     if (group_rows <= 0 || nparts <= 0 || part < 0 || part >= nparts) SRX_FAIL("srx_trace_pass_adaptive: bad row interleave (group_rows, part, nparts)");
     const uint64_t npix = (uint64_t)camera->res_x * camera->res_y;
     if (npix > 0x00FFFFFFull) SRX_FAIL("srx_trace_pass_adaptive: more than 2^24-1 pixels is not supported");
-    if (ensure_sample_buffer(r, npix)) return 1;
     if (begin_call(r)) return 1;
+    if (ensure_sample_buffer(r, npix)) return 1;
     GCamera cam;
     std::memcpy(&cam, camera, sizeof(cam));
     GRows rm;
@@ -381,6 +512,7 @@ extern "C" int srx_process_rays(srx_renderer* r, const float* org3, const float*
     const uint64_t chunk = r->capacity / (1 + fan);
     if (chunk == 0) SRX_FAIL("srx_process_rays: ray_capacity too small");
     float *d_o = nullptr, *d_d = nullptr; unsigned long long* d_k = nullptr;
+    struct Free { float*& a; float*& b; unsigned long long*& c; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); } } free_all{d_o, d_d, d_k};
     SRX_HIP(hipMalloc((void**)&d_o, (size_t)n * 12)); SRX_HIP(hipMalloc((void**)&d_d, (size_t)n * 12)); SRX_HIP(hipMalloc((void**)&d_k, (size_t)n * 8));
     int rc = 0;
     do {
@@ -398,7 +530,6 @@ extern "C" int srx_process_rays(srx_renderer* r, const float* org3, const float*
             }
         }
     } while (0);
-    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_k);
     if (rc) return rc;
     return end_call(r, counters);
 }

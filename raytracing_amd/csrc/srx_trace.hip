@@ -193,12 +193,15 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     // XCD-aware block -> ray-range map: blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), so
     // XCD x works on the x-th contiguous eighth of the queue (queue order follows pixel / parent order).
     // Speed only; any placement gives the same results.
-    const uint32_t nblk = gridDim.x;
+    // (the grid may have been sized for more rays than there are, a.n_ptr: the map is made over the blocks that have
+    // rays, so that they are still dealt evenly over the XCDs; the others leave at once)
+    const uint32_t n_rays = a.n_ptr ? min(*a.n_ptr, a.n) : a.n;
+    const uint32_t nblk = a.n_ptr ? min(gridDim.x, ((n_rays + SRX_RAYS_PER_BLOCK - 1u) / SRX_RAYS_PER_BLOCK + 7u) & ~7u) : gridDim.x;
+    if (blockIdx.x >= nblk) return;
     const uint32_t per_xcd = (nblk + 7u) >> 3;
     const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     // ray j of this octet; the block's rays are contiguous in the queue
     const uint32_t ray0 = lblock * SRX_RAYS_PER_BLOCK + oct;
-    const uint32_t n_rays = a.n;
     float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {d, o.x}, {o.yz, inv.xy}, {inv.z, fused}
     float2* const s_pt = (float2*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening, quantised direction (bits)
     uint32_t* const s_spilled = (uint32_t*)(s_pt + K * SRX_OCTETS_PER_BLOCK);   // [octets]: entries parked in memory (SPILL)

@@ -31,6 +31,11 @@ def _dev_ptr(x):
     if hasattr(x, "data_ptr"):
         if not x.is_cuda or not x.is_contiguous():
             raise ValueError("framebuffers must be contiguous device tensors")
+        # The library works on streams of its own, which do not order against torch's: whatever torch has queued for
+        # this tensor (its zero fill, a priority update) must be over before the library touches it. The calls
+        # themselves return only when their work is complete, so nothing is needed on the way back.
+        import torch
+        torch.cuda.current_stream(x.device).synchronize()
         return C.c_void_p(x.data_ptr())
     return C.c_void_p(int(x))
 

@@ -210,3 +210,67 @@ def test_mutated_files_are_loaded_or_refused(tmp_path):
         except _lib.SrxError:
             refused += 1
     assert loaded + refused == 300 and refused > 50
+
+
+def test_crafted_numbers_cannot_pass_the_range_checks(tmp_path):
+    """Offsets, strides and counts are JSON doubles: negative, fractional or huge values (whose size_t casts and sums would
+    wrap past a plain `off + len > size` test) must be refused, and a PNG whose zlib stream inflates to more than the
+    image needs must not be expanded."""
+    import struct, zlib
+
+    def scene(mutate, with_image=False):
+        g = GlbWriter()
+        tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.5]], np.float32)
+        prim = {"attributes": {"POSITION": g.accessor(tri, "VEC3")}, "indices": g.accessor(np.array([0, 1, 2], np.uint16), "SCALAR")}
+        if with_image:
+            t = g.image(np.full((4, 4, 3), 200, np.uint8))
+            g.js["materials"].append({"pbrMetallicRoughness": {"baseColorTexture": {"index": t}}})
+            prim["material"] = 0
+            prim["attributes"]["TEXCOORD_0"] = g.accessor(np.array([[0, 0], [1, 0], [0, 1]], np.float32), "VEC2")
+        g.js["meshes"].append({"primitives": [prim]})
+        g.js["nodes"] = [{"mesh": 0}, {"camera": 0}]
+        g.js["cameras"].append({"type": "perspective", "perspective": {"aspectRatio": 1.0, "yfov": 0.7}})
+        mutate(g)
+        return g
+
+    def acc(i): return lambda g, i=i: g.js["accessors"][0].update(i)
+    def view(i): return lambda g, i=i: g.js["bufferViews"][0].update(i)
+    def img_view(i):
+        def m(g, i=i):
+            g.js["bufferViews"][g.js["images"][0]["bufferView"]].update(i)
+        return m
+    cases = [
+        ("neg_offset", acc({"byteOffset": -8}), False),
+        ("huge_count", acc({"count": 2 ** 61}), False),
+        ("huge_count_stride", lambda g: (g.js["accessors"][0].update({"count": 2 ** 61 + 1}), g.js["bufferViews"][0].update({"byteStride": 8})), False),
+        ("wrap_stride", lambda g: (g.js["accessors"][0].update({"count": 3}), g.js["bufferViews"][0].update({"byteStride": 2 ** 63})), False),
+        ("fraction", acc({"byteOffset": 0.5}), False),
+        ("view_neg", view({"byteOffset": -4}), False),
+        ("view_huge", view({"byteOffset": 1.8e19}), False),
+        ("img_offset_2_64", img_view({"byteOffset": 1.8446744073709552e19}), True),
+        ("img_len_huge", img_view({"byteLength": 2 ** 62}), True),
+        ("img_neg", img_view({"byteOffset": -1}), True),
+    ]
+    for name, mut, with_image in cases:
+        p = tmp_path / (name + ".glb")
+        scene(mut, with_image).write(p)
+        with pytest.raises(_lib.SrxError):
+            gltf.load_gltf_file(p, 4, 4)
+    scene(lambda g: None, True).write(tmp_path / "ok.glb")
+    assert len(gltf.load_gltf_file(tmp_path / "ok.glb", 4, 4).tris) == 1
+
+    # a 4x4 image whose IDAT inflates to 64 MB
+    def chunk(ty, body):
+        return struct.pack(">I", len(body)) + ty + body + struct.pack(">I", zlib.crc32(ty + body))
+    bomb = (b"\\x89PNG\\r\\n\\x1a\\n".decode("unicode_escape").encode("latin1") + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(b"\\0" * (64 << 20), 9)) + chunk(b"IEND", b""))
+
+    def with_bomb(g):
+        bv = g.js["bufferViews"][g.js["images"][0]["bufferView"]]
+        while len(g.bin) % 4:
+            g.bin.append(0)
+        bv["byteOffset"], bv["byteLength"] = len(g.bin), len(bomb)
+        g.bin += bomb
+    scene(with_bomb, True).write(tmp_path / "bomb.glb")
+    with pytest.raises(_lib.SrxError, match="more data than the image needs"):
+        gltf.load_gltf_file(tmp_path / "bomb.glb", 4, 4)
