@@ -163,7 +163,7 @@ def adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, barrier):
             visit += 1
         barrier()
         t1 = time.perf_counter()
-        seen = tiles.allreduce_error_map(err, NC.error_map(accum, aux, err, interleave=share))
+        seen = tiles.allreduce_error_map(err, NC.error_map(accum, aux, err, interleave=share), H, W)
         NC.analyze_noise(err, seen)
         NC.balance(seen, prio)
         torch.cuda.synchronize()
@@ -239,11 +239,38 @@ def main():
     del scratch
     for p in range(0, args.warmup, B):
         RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share, n_passes=min(B, args.warmup - p))
+    # The two exchange steps of a multi-GPU frame, inside the timed region: the adaptive-sampling controller's payload
+    # (every rank's rows of the per-pixel error map, all-gathered, + the minimum sample count) and the framebuffer
+    # all-gather (main + aux in one collective). Through the library's own srx_group (RCCL loaded by libsrx.so) when the
+    # ranks sit on GPUs of their own; over torch.distributed otherwise (gloo rehearsals) or if the group cannot be made.
+    grp, exchange_path, NCx, err = None, "none (one rank)", None, None
     if world > 1:
-        # warm-up of the two exchanges as well (communicator set-up, index tensors); they only fill in the other ranks' rows
-        sums, mins = tiles.rows_noise_stats(accum, aux, H, W, my_rows)
-        tiles.allreduce_noise_stats(sums, mins)
-        tiles.gather_framebuffer_interleaved([accum, aux], H, W)
+        NCx = engine.NoiseController(W, H, seed=args.seed, device=local_rank)
+        err = torch.zeros(W * H, dtype=torch.float32, device="cuda")
+        exchange_path = "torch.distributed (" + args.backend + "), rows packed with torch index ops"
+        if args.backend == "nccl" and not args.one_device and os.environ.get("SRX_BENCH_EXCHANGE", "srx") == "srx":
+            try:
+                grp = tiles.Group.from_torch_dist()
+                exchange_path = "srx_group (C-ABI, RCCL)"
+            except Exception as e:                      # noqa: BLE001  (reported in the JSON line, not hidden)
+                exchange_path += f"; srx_group unavailable: {e}"
+        ok = torch.tensor([1 if grp is not None else 0], device="cuda")
+        dist.all_reduce(ok if args.backend == "nccl" else ok.cpu(), op=dist.ReduceOp.MIN)
+        if grp is not None and int(ok.item()) == 0:     # some rank has no group: nobody uses it
+            grp.close(); grp = None
+
+    def exchange():
+        if world <= 1:
+            return
+        seen = NCx.error_map(accum, aux, err, interleave=share)
+        if grp is not None:
+            grp.complete_error_map(err, seen, H, W)
+            grp.gather_framebuffer(accum, aux, H, W)
+        else:
+            tiles.allreduce_error_map(err, seen, H, W)
+            tiles.gather_framebuffer_interleaved([accum, aux], H, W)
+
+    exchange()      # warm-up of the exchanges as well (communicator set-up); they only fill in the other ranks' rows
     barrier()
     t0 = time.perf_counter()
     tot = {}
@@ -252,11 +279,7 @@ def main():
                           n_passes=min(B, args.warmup + args.steps - p))
         for k, v in c.items():
             tot[k] = tot.get(k, 0) + v
-    if world > 1:
-        # the two exchange steps: noise statistics all-reduce (KBs) and framebuffer all-gather over xGMI
-        sums, mins = tiles.rows_noise_stats(accum, aux, H, W, my_rows)
-        tiles.allreduce_noise_stats(sums, mins)
-        tiles.gather_framebuffer_interleaved([accum, aux], H, W)
+    exchange()
     barrier()
     dt = time.perf_counter() - t0
 
@@ -353,6 +376,7 @@ def main():
                             f"{desc.name}, {len(desc.tris)} tris, {W}x{H}, 1 spp per step, max_generations {desc.max_generations}, "
                             f"monte_carlo_max {desc.monte_carlo_max} (not the headline workload)",
                 "parallelism": f"interleaved tile rows x{world}, scene replicated",
+                "exchange": exchange_path,
                 "rays_per_step": rays / args.steps,
                 "shadow_rays_per_step": agg["shadows_cast"] / args.steps,
                 "ray_capacity": args.ray_capacity,

@@ -6,16 +6,41 @@
 // SceneManager.h:193-237), write the raw frame (FileManager::writeRawFile, FileLoading.h:166-182) and the canvas.
 // Plain C++17, no HIP headers:  g++ -std=c++17 -Iinclude examples/render_glb.cpp -Lraytracing_amd -lsrx -o examples/render_glb
 //
-// usage: render_glb scene.glb res_x res_y subdiv spp seed out.raw [out.png]
+// usage: render_glb scene.glb res_x res_y subdiv spp seed out.raw [out.png] [--rank R --nranks N --id-file F [--device D]]
+// With --id-file the process is one rank of a multi-GPU render (one process per GPU): it renders its tile rows and the
+// frame is gathered through spatialray::Group (srx_group, RCCL); rank 0 writes the files.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <thread>
 #include "spatialray_adapter.hpp"
 
 using namespace spatialray;
 
 int main(int argc, char** argv) {
-    if (argc < 8) { std::fprintf(stderr, "usage: %s scene.glb res_x res_y subdiv spp seed out.raw [out.png]\n", argv[0]); return 2; }
+    if (argc < 8) {
+        std::fprintf(stderr, "usage: %s scene.glb res_x res_y subdiv spp seed out.raw [out.png] [--rank R --nranks N --id-file F [--device D]]\n"
+                             "  one process per GPU: every rank renders its tile rows (4-row groups dealt round-robin), then the frame is gathered\n"
+                             "  over RCCL; rank 0 writes the communicator id to F, the other ranks read it from there; only rank 0 writes files\n", argv[0]);
+        return 2;
+    }
     try {
+        int rank = 0, nranks = 1, device = 0;
+        std::string id_file;
+        int n_pos = argc;
+        for (int i = 8; i < argc; i++) {
+            const std::string a = argv[i];
+            if (a.rfind("--", 0) == 0 && n_pos == argc) n_pos = i;
+            if (a == "--rank" && i + 1 < argc) rank = std::atoi(argv[++i]);
+            else if (a == "--nranks" && i + 1 < argc) nranks = std::atoi(argv[++i]);
+            else if (a == "--id-file" && i + 1 < argc) id_file = argv[++i];
+            else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+        }
+        const bool grouped = !id_file.empty();
+        if (grouped && (nranks < 1 || rank < 0 || rank >= nranks)) throw std::runtime_error("bad --rank / --nranks");
+        argc = n_pos;
         const int res_x = std::atoi(argv[2]), res_y = std::atoi(argv[3]), subdiv = std::atoi(argv[4]), spp = std::atoi(argv[5]);
         const uint64_t seed = std::strtoull(argv[6], nullptr, 10);
 
@@ -26,15 +51,50 @@ int main(int argc, char** argv) {
         PackagedScene PS(file.tris);                            // Scene::package()
         PS.materials = file.materials; PS.textures = file.textures; PS.lights = file.suns;
 
-        RayEngine RE(0, 1u << 24);
+        RayEngine RE(device, 1u << 24);
         RE.load_scene(&PS);
+        // multi-GPU: the communicator (RayEngine's constructor made `device` current)
+        std::unique_ptr<Group> group;
+        if (grouped) {
+            std::vector<char> id(128);
+            if (rank == 0) {
+                id = Group::unique_id();
+                std::ofstream f(id_file + ".tmp", std::ios::binary);
+                f.write(id.data(), 128);
+                f.close();
+                std::rename((id_file + ".tmp").c_str(), id_file.c_str());
+            } else {
+                for (int tries = 0;; tries++) {
+                    std::ifstream f(id_file, std::ios::binary);
+                    if (f && f.read(id.data(), 128)) break;
+                    if (tries > 600) throw std::runtime_error("no communicator id appeared in " + id_file);
+                    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                }
+            }
+            group.reset(new Group(id, rank, nranks));
+        }
 
         FrameBuffers frame(res_x, res_y);
         Casting_Diagnostics stats;
         for (int pass = 0; pass < spp; pass++) {
-            const srx_counters c = RE.trace_pass(file.camera, 0, 0, res_x, res_y, (uint32_t)pass, seed, frame.raw_output, frame.aux_output);
+            // this rank's rows of the pass (all of them without a group): SceneManager::assign_iterative_groups, SceneManager.h:441-459
+            const srx_counters c = RE.trace_pass_interleaved(file.camera, 0, 0, res_x, res_y, 4, rank, nranks, (uint32_t)pass, seed, frame.raw_output,
+                                                             frame.aux_output);
             stats.rays_processed += (long long)c.rays_processed;   // parent + child rays, SceneManager.h:83-90
             stats.shadows_cast += (long)c.shadows_cast;
+        }
+        if (group) {
+            group->gather_framebuffer(frame.raw_output, frame.aux_output, res_x, res_y, 4);     // SceneManager::get_screen_update, :801-815
+            // the job's ray counts: SceneManager::gather_thread_stats (:488-502) sums the threads' counters
+            double h_sums[2] = {(double)stats.rays_processed, (double)stats.shadows_cast};
+            double* d_sums = nullptr;
+            check(srx_buffer_create(sizeof(h_sums), (void**)&d_sums), "srx_buffer_create");
+            check(srx_buffer_write(d_sums, sizeof(h_sums), h_sums), "srx_buffer_write");
+            group->allreduce(d_sums, 2, nullptr, 0);
+            check(srx_buffer_read(d_sums, sizeof(h_sums), h_sums), "srx_buffer_read");
+            srx_buffer_destroy(d_sums);
+            stats.rays_processed = (long long)h_sums[0]; stats.shadows_cast = (long)h_sums[1];
+            if (rank != 0) return 0;
         }
         FileManager::writeRawFile(frame.raw_output, res_x, res_y, argv[7]);
         if (argc > 8) {

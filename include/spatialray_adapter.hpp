@@ -171,6 +171,37 @@ public:
     }
 };
 
+// One rank of a multi-GPU render (one process per GPU): what SceneManager's threads hand over in shared memory
+// (get_screen_update SceneManager.h:801-815, gather_thread_stats :488-502, the error terms of analyze_noise :559-579)
+// travels through srx_group (RCCL). Rank 0 makes the id, the host passes its 128 bytes to the other ranks.
+class Group {
+public:
+    static std::vector<char> unique_id() { std::vector<char> id(128); check(srx_group_unique_id(id.data()), "srx_group_unique_id"); return id; }
+    Group(const std::vector<char>& id128, int rank, int nranks) {
+        if (id128.size() != 128) throw std::runtime_error("Group: the id is 128 bytes");
+        check(srx_group_create(id128.data(), rank, nranks, &g_), "srx_group_create");
+        rank_ = rank; nranks_ = nranks;
+    }
+    ~Group() { srx_group_destroy(g_); }
+    Group(const Group&) = delete;
+    Group& operator=(const Group&) = delete;
+    int rank() const { return rank_; }
+    int nranks() const { return nranks_; }
+    // every rank's tile rows (groups of group_rows rows dealt round-robin) into every rank's frame, main + aux in one collective
+    void gather_framebuffer(float* d_accum4, float* d_aux4, int res_x, int res_y, int group_rows) {
+        check(srx_group_gather_framebuffer(g_, d_accum4, d_aux4, res_x, res_y, group_rows), "srx_group_gather_framebuffer");
+    }
+    void allgather_rows(float* d_frame, int floats_per_pixel, int res_x, int res_y, int group_rows) {
+        check(srx_group_allgather_rows(g_, d_frame, floats_per_pixel, res_x, res_y, group_rows), "srx_group_allgather_rows");
+    }
+    void allreduce(double* d_sums, uint32_t n_sums, int32_t* d_mins, uint32_t n_mins) {
+        check(srx_group_allreduce(g_, d_sums, n_sums, d_mins, n_mins), "srx_group_allreduce");
+    }
+private:
+    srx_group* g_ = nullptr;
+    int rank_ = 0, nranks_ = 1;
+};
+
 // FileManager (FileLoading.h): scene in, raw frame out
 namespace FileManager {
 struct GltfScene {                                               // what parseGLTFData leaves in Scene, flattened (FileLoading.h:438-782)

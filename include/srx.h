@@ -266,10 +266,11 @@ int srx_xorgen_stream(const uint64_t* seed4, uint32_t n_pools, uint32_t n_scalar
  * (SceneManager::raw_output / aux_output, SceneManager.h:288-289, filled at :370-380); here they live on the device as
  * res_x * res_y float4 {running mean r, g, b, sample count}. srx_buffer_create returns zeroed device memory (a
  * framebuffer is res_x * res_y * 16 bytes, a canvas for srx_post_process res_x * res_y * 4), srx_buffer_read copies it
- * to the host, srx_buffer_clear zeroes it again (`SceneManager::reset_blocks`, SceneManager.h:478-487). */
+ * to the host (srx_buffer_write the other way), srx_buffer_clear zeroes it again (`SceneManager::reset_blocks`, SceneManager.h:478-487). */
 int srx_buffer_create(uint64_t bytes, void** d_out);
 void srx_buffer_destroy(void* d_buf);
 int srx_buffer_read(const void* d_buf, uint64_t bytes, void* host_out);
+int srx_buffer_write(void* d_buf, uint64_t bytes, const void* host_in);
 int srx_buffer_clear(void* d_buf, uint64_t bytes);
 
 /* ---- output stage ---------------------------------------------------------------------------
@@ -306,6 +307,39 @@ int srx_gltf_load(const char* path, srx_gltf** out);
 void srx_gltf_destroy(srx_gltf* g);
 int srx_gltf_get(const srx_gltf* g, const srx_tri** tris, uint32_t* n_tris, const srx_material** materials, uint32_t* n_materials,
                  const srx_texture** textures, uint32_t* n_textures, const srx_sun** suns, uint32_t* n_suns, srx_camera* camera);
+
+/* ---- multi-GPU exchange: one process per GPU, scene replicated, tile rows dealt round-robin
+ * (srx_trace_pass_interleaved), nothing exchanged on the sample path. What the reference's worker threads hand over in
+ * shared memory becomes a collective over RCCL / xGMI (RCCL is loaded at run time; single-GPU use does not need it):
+ *   SceneManager::get_screen_update (SceneManager.h:801-815: every block's pixels into one output)  -> srx_group_gather_framebuffer
+ *   the per-pixel error terms analyze_noise sums (:559-579)                                         -> srx_group_allgather_rows on the error map
+ *   SceneManager::gather_thread_stats (:488-502: minimum samples) and counters                      -> srx_group_allreduce
+ * Bootstrap: rank 0 calls srx_group_unique_id and hands the 128 bytes to the other ranks by any means (a file, MPI,
+ * torch.distributed); every rank then calls srx_group_create with its GPU current. Calls are collective (every rank
+ * makes them in the same order) and return when the exchange is complete. */
+typedef struct srx_group srx_group;
+int srx_group_unique_id(void* id128);
+int srx_group_create(const void* id128, int32_t rank, int32_t nranks, srx_group** out);
+void srx_group_destroy(srx_group* g);
+int srx_group_rank(const srx_group* g, int32_t* rank, int32_t* nranks);
+/* In-place all-gather of float4 framebuffers (device) whose rows of THIS rank are valid, rows dealt in groups of
+ * group_rows (rank = part, nranks = nparts of srx_trace_pass_interleaved): main and aux buffer (d_aux4 may be NULL) travel
+ * in ONE collective, each rank's rows once. */
+int srx_group_gather_framebuffer(srx_group* g, float* d_accum4, float* d_aux4, int32_t res_x, int32_t res_y, int32_t group_rows);
+/* The same for any per-pixel device array of floats_per_pixel floats (the error map of srx_noise_error_map: 1). After it
+ * every rank holds the complete map and srx_noise_analyze gives the same regions on every rank as on one GPU. */
+int srx_group_allgather_rows(srx_group* g, float* d_frame, int32_t floats_per_pixel, int32_t res_x, int32_t res_y, int32_t group_rows);
+/* In-place all-reduce over the ranks: d_sums[n_sums] doubles are summed, d_mins[n_mins] int32 take the minimum (device). */
+int srx_group_allreduce(srx_group* g, double* d_sums, uint32_t n_sums, int32_t* d_mins, uint32_t n_mins);
+/* The row packing on its own, for a host that brings its own transport: a part's rows of a frame packed into a slot of
+ * srx_rows_slot_floats() floats per frame (the size of the largest share, so slots are equal), and all parts' slots
+ * (slot_stride_floats apart, this frame at buffer_offset_floats inside each) scattered back into a frame; skip_part's rows
+ * are left as they are (-1: none). `stream` = hipStream_t, asynchronous. */
+uint64_t srx_rows_slot_floats(int32_t floats_per_pixel, int32_t res_x, int32_t res_y, int32_t group_rows, int32_t nparts);
+int srx_rows_pack(const float* d_frame, int32_t floats_per_pixel, int32_t res_x, int32_t res_y, int32_t group_rows, int32_t part,
+                  int32_t nparts, float* d_slot, void* stream);
+int srx_rows_unpack(const float* d_slots, uint64_t slot_stride_floats, uint64_t buffer_offset_floats, int32_t floats_per_pixel, int32_t res_x,
+                    int32_t res_y, int32_t group_rows, int32_t nparts, int32_t skip_part, float* d_frame, void* stream);
 
 #ifdef __cplusplus
 }

@@ -170,6 +170,11 @@ extern "C" int srx_buffer_read(const void* d_buf, uint64_t bytes, void* host_out
     SRX_HIP(hipMemcpy(host_out, d_buf, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
+extern "C" int srx_buffer_write(void* d_buf, uint64_t bytes, const void* host_in) {
+    if (!d_buf || !host_in) SRX_FAIL("srx_buffer_write: null argument");
+    SRX_HIP(hipMemcpy(d_buf, host_in, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
 extern "C" int srx_buffer_clear(void* d_buf, uint64_t bytes) {
     if (!d_buf) SRX_FAIL("srx_buffer_clear: null argument");
     SRX_HIP(hipMemset(d_buf, 0, bytes));

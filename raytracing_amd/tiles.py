@@ -132,6 +132,105 @@ def _gather_interleaved(bufs, height, width, tile):
     return bufs
 
 
+# ---------------------------------------------------------------- the C-ABI exchange (csrc/srx_group.hip)
+class Group:
+    """`srx_group` of include/srx.h: the exchange steps through the library itself (RCCL loaded by libsrx.so, row
+    packing in its kernels), one rank per process with its GPU current. `unique_id()` on rank 0, hand the 128 bytes to
+    the other ranks, then `Group(id, rank, nranks)`; `from_torch_dist()` does the hand-over with torch.distributed."""
+
+    def __init__(self, id128: bytes, rank: int, nranks: int):
+        import ctypes as C
+        from . import _lib
+        self.L, self.C, self._check = _lib.lib(), C, _lib.check
+        self.h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id128), 128)
+        self._check(self.L.srx_group_create(buf, C.c_int32(rank), C.c_int32(nranks), C.byref(self.h)), "srx_group_create")
+        self.rank, self.nranks = rank, nranks
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().srx_group_unique_id(buf), "srx_group_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_dist(cls):
+        """Every rank of an initialised torch.distributed job calls this: rank 0's id travels by broadcast."""
+        rank, world = (dist.get_rank(), dist.get_world_size()) if _is_dist() else (0, 1)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return cls(box[0], rank, world)
+
+    def close(self):
+        if self.h:
+            self.L.srx_group_destroy(self.h)
+            self.h = self.C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ptr(self, t):
+        if t is None:
+            return None
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("the exchange takes contiguous device tensors")
+        torch.cuda.current_stream(t.device).synchronize()
+        return self.C.c_void_p(t.data_ptr())
+
+    def gather_framebuffer(self, accum4, aux4, height, width, tile=TILE):
+        C = self.C
+        self._check(self.L.srx_group_gather_framebuffer(self.h, self._ptr(accum4), self._ptr(aux4), C.c_int32(width), C.c_int32(height),
+                                                        C.c_int32(tile)), "srx_group_gather_framebuffer")
+
+    def allgather_rows(self, frame, floats_per_pixel, height, width, tile=TILE):
+        C = self.C
+        self._check(self.L.srx_group_allgather_rows(self.h, self._ptr(frame), C.c_int32(floats_per_pixel), C.c_int32(width), C.c_int32(height),
+                                                    C.c_int32(tile)), "srx_group_allgather_rows")
+
+    def allreduce(self, sums=None, mins=None):
+        """In place: `sums` (float64 device tensor) summed over the ranks, `mins` (int32 device tensor) minimised."""
+        C = self.C
+        if sums is not None and sums.dtype != torch.float64 or mins is not None and mins.dtype != torch.int32:
+            raise ValueError("sums must be float64, mins int32")
+        self._check(self.L.srx_group_allreduce(self.h, self._ptr(sums), C.c_uint32(0 if sums is None else sums.numel()), self._ptr(mins),
+                                               C.c_uint32(0 if mins is None else mins.numel())), "srx_group_allreduce")
+
+    def complete_error_map(self, err, min_samples, height, width, tile=TILE):
+        """The controller's exchange: every rank filled its own rows of the error map (`srx_noise_error_map`); all-gather
+        them (each rank's rows travel once, no arithmetic: the complete map is bit-identical to one GPU's, so
+        `analyze_noise` gives the same regions everywhere) and take the minimum sample count. Returns that minimum."""
+        self.allgather_rows(err, 1, height, width, tile)
+        mn = torch.tensor([int(min_samples)], dtype=torch.int32, device=err.device)
+        self.allreduce(None, mn)
+        return int(mn.item())
+
+
+def rows_pack_unpack_roundtrip(frames_by_part, floats_per_pixel, height, width, tile=TILE):
+    """What N ranks' gather does, played on ONE GPU through srx_rows_pack / srx_rows_unpack (tests): part p's frame
+    holds valid rows of part p only; returns the frame every rank would end up with."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    n = len(frames_by_part)
+    slot = int(L.srx_rows_slot_floats(C.c_int32(floats_per_pixel), C.c_int32(width), C.c_int32(height), C.c_int32(tile), C.c_int32(n)))
+    slots = torch.full((n * slot,), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for p, f in enumerate(frames_by_part):
+        _lib.check(L.srx_rows_pack(C.c_void_p(f.data_ptr()), C.c_int32(floats_per_pixel), C.c_int32(width), C.c_int32(height), C.c_int32(tile),
+                                   C.c_int32(p), C.c_int32(n), C.c_void_p(slots.data_ptr() + 4 * p * slot), None), "srx_rows_pack")
+    out = torch.full_like(frames_by_part[0], float("nan"))
+    _lib.check(L.srx_rows_unpack(C.c_void_p(slots.data_ptr()), C.c_uint64(slot), C.c_uint64(0), C.c_int32(floats_per_pixel), C.c_int32(width),
+                                 C.c_int32(height), C.c_int32(tile), C.c_int32(n), C.c_int32(-1), C.c_void_p(out.data_ptr()), None), "srx_rows_unpack")
+    torch.cuda.synchronize()
+    return out
+
+
 def allreduce_noise_stats(sums: torch.Tensor, min_samples: torch.Tensor):
     """Combine adaptive-sampling statistics: `sums` (any shape, summed) and `min_samples` (minimum)."""
     if _is_dist():
@@ -140,13 +239,19 @@ def allreduce_noise_stats(sums: torch.Tensor, min_samples: torch.Tensor):
     return sums, min_samples
 
 
-def allreduce_error_map(err: torch.Tensor, min_samples: int):
-    """Completes the per-pixel error map of the adaptive-sampling controller: every rank filled its own rows and
-    left the others 0 (`srx_noise_error_map`), so all-reduce(sum) yields the whole map on every rank; the minimum
-    sample count is all-reduce(min) (`gather_thread_stats`, SceneManager.h:492-501). Returns the global minimum."""
+def allreduce_error_map(err: torch.Tensor, min_samples: int, height: int = 0, width: int = 0, tile: int = TILE):
+    """Completes the per-pixel error map of the adaptive-sampling controller over torch.distributed (the transport of
+    the CPU tests and rehearsals; on GPUs `Group.complete_error_map` does it through the library): every rank filled
+    its own rows and left the others 0 (`srx_noise_error_map`). With the frame's shape given, the rows are ALL-GATHERED
+    (each rank's rows travel once: 1/N of the map per rank, no arithmetic, so the map is bit-identical to one GPU's);
+    without it they are summed with an all-reduce (twice the traffic; adding zeros is exact too). The minimum sample
+    count is all-reduce(min) (`gather_thread_stats`, SceneManager.h:492-501). Returns the global minimum."""
     if not _is_dist():
         return int(min_samples)
-    _host_staged(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM), err)
+    if height and width:
+        gather_framebuffer_interleaved(err.view(height * width, 1), height, width, tile)
+    else:
+        _host_staged(lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM), err)
     mn = torch.tensor([int(min_samples)], dtype=torch.int64)
     if dist.get_backend() != "gloo":
         mn = mn.to(err.device)

@@ -111,17 +111,32 @@ def _worker_errmap(rank, world, port, H, W, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from raytracing_amd import tiles
-    full = torch.rand(H, W, generator=torch.Generator().manual_seed(3))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from noise_inputs import framebuffers
+    from oracle import sro
+    acc, aux = framebuffers(W, H, seed=5)        # framebuffers with structure for the controller to split on
+    full = torch.from_numpy(sro.noise_error_map(acc, aux)[0].reshape(H, W).copy())
     rows = tiles.interleaved_rows(rank, world, H)
     mine = torch.zeros(H, W)
     mine[rows] = full[rows]                      # what srx_noise_error_map leaves on this rank
-    mn = tiles.allreduce_error_map(mine.view(-1), 40 + rank)
-    q.put((rank, bool(torch.equal(mine, full)), mn))
+    mine2 = mine.clone()
+    mn = tiles.allreduce_error_map(mine.view(-1), 40 + rank)                     # all-reduce(sum) of the zero-filled maps
+    mn2 = tiles.allreduce_error_map(mine2.view(-1), 40 + rank, H, W)             # all-gather of each rank's rows (what the GPUs do)
+    # the controller's analysis on the exchanged map gives the region list of the single-rank analysis (the same bytes go in)
+    regs = []
+    for m in (mine2, full):
+        ON = sro.OracleNoise(W, H, seed=5, minimum_samples=4)
+        for _ in range(3):
+            ON.analyze(m.numpy().astype("float32"), 10 if _ == 0 else 100)
+        regs.append(ON.regions())
+    same = all(bool((a == b).all()) for a, b in zip(regs[0], regs[1])) and len(regs[0][0]) > 1
+    q.put((rank, bool(torch.equal(mine, full)) and bool(torch.equal(mine2, full)) and same, min(mn, mn2) if mn == mn2 else -1))
     dist.destroy_process_group()
 
 
 def test_error_map_allreduce_world2():
-    H, W, world, port = 22, 7, 2, 33500 + os.getpid() % 2000
+    H, W, world, port = 64, 96, 2, 33500 + os.getpid() % 2000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker_errmap, args=(r, world, port, H, W, q)) for r in range(world)]
