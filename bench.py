@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--adaptive", type=int, default=0, metavar="MIN_SAMPLES",
                     help="not the headline run: after the timed steps, run the adaptive-sampling loop (controller's minimum_samples = "
                          "MIN_SAMPLES, analysis every 4 visits) and report it under config.adaptive")
+    ap.add_argument("--fast-build", action="store_true", help="not the headline run: package the scene with srx_package_create_fast (a different tree, "
+                    "tight leaves; hits equal the reference tree's through the order tables) and report the same metric over it")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: exchange staged through the host)")
     ap.add_argument("--passes-per-call", type=int, default=0, metavar="B",
                     help="sample passes (steps) that share their kernel launches; 0 = the number of ranks, so a rank's launches stay as "
@@ -211,7 +213,7 @@ def main():
         desc = scenes.diffuse_box(args.tris, res=(W, H), subdiv=8)
     cam = desc.camera
     t0 = time.perf_counter()
-    PS = engine.package(desc)
+    PS = engine.package(desc, fast=args.fast_build)
     t_pack = time.perf_counter() - t0
     RE = engine.RayEngine(local_rank)
     RE.load_scene(PS)
@@ -381,6 +383,8 @@ def main():
                 "shadow_rays_per_step": agg["shadows_cast"] / args.steps,
                 "ray_capacity": args.ray_capacity,
                 "scene_package_s": t_pack,
+                "builder": "srx_package_create_fast (opt-in: a different tree, not the reference's triangle numbering)" if args.fast_build
+                           else "srx_package_create (bit-compatible with Scene::package)",
                 "stack_depth": RE.stack_bound(),
                 "passes_per_call": B,
             },

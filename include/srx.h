@@ -127,6 +127,15 @@ int srx_package_create(const srx_tri* tris, uint32_t n_tris, srx_package** out);
 int srx_package_get(const srx_package* pkg, const void** nodes, uint32_t* n_nodes, const void** packets,
                     uint32_t* n_packets, const void** tris, uint32_t* n_tris);
 void srx_package_destroy(srx_package* pkg);
+/* A DIFFERENT tree over the same triangles, built fast: parallel binned SAH, tight leaf boxes, greedy
+ * 8-wide collapse; same record formats, so srx_package_get / srx_scene_create take it as they take the other. Opt-in: the
+ * reference's build (BVH.h:98-180, :581-653) defines the numbering of tri_data, and a different tree numbers the triangles
+ * differently; it also leaves out the reference's origin-grown leaf boxes (quirk Q1) and the invisibility of exactly flat
+ * axis-aligned subtrees (Q3). Closest hits are the same triangles with the same t, u, v except where two triangles tie. */
+int srx_package_create_fast(const srx_tri* tris, uint32_t n_tris, srx_package** out);
+/* order[k] = index of the input triangle that tri_data[k] (and so a hit's tri_index k) was packed from, for a package of
+ * either builder: the remap between the two numberings. */
+int srx_package_get_order(const srx_package* pkg, const uint32_t** order, uint32_t* n);
 
 /* Lookup tables: `VecLib::prep` arccos table (VecLib.cpp:391-398) and `PDF::prep` (PDF.h:83-123). */
 int srx_build_tables(float* arccos2048, float* pdf1m);

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SRX_LIB", os.path.join(HERE, "libsrx.so"))
 # every symbol include/srx.h declares; tests check the library exports all of them
 EXPORTS = [
     "srx_last_error", "srx_init",
-    "srx_package_create", "srx_package_get", "srx_package_destroy", "srx_build_tables",
+    "srx_package_create", "srx_package_create_fast", "srx_package_get", "srx_package_get_order", "srx_package_destroy", "srx_build_tables",
     "srx_scene_create", "srx_scene_destroy", "srx_scene_stack_bound", "srx_scene_stack_spills",
     "srx_cast_closest", "srx_cast_closest_device", "srx_cast_closest_device_static", "srx_cast_shadow", "srx_cast_shadow_device",
     "srx_renderer_create", "srx_renderer_destroy", "srx_renderer_set_timing",

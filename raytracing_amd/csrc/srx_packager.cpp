@@ -327,34 +327,58 @@ void pack_tri(const HTri& t, uint8_t* out) {                      // Tri::pack P
     std::memcpy(out, f, 196);
 }
 
+// Tri ctor Primitives.h:238-252
+void make_htri(const srx_tri& in, HTri& t) {
+    vset(t.p1, in.p); vset(t.p2, in.p + 3); vset(t.p3, in.p + 6);
+    t.uv1[0] = in.uv[0]; t.uv1[1] = in.uv[1]; t.uv2[0] = in.uv[2]; t.uv2[1] = in.uv[3];
+    t.uv3[0] = in.uv[4]; t.uv3[1] = in.uv[5];
+    for (int k = 0; k < 3; k++) t.mid[k] = (t.p1[k] + t.p2[k] + t.p3[k]) / 3;
+    v3 m; vmax(m, t.p2, t.p3); vmax(t.bmax, t.p1, m);
+    vmin(m, t.p2, t.p3); vmin(t.bmin, t.p1, m);
+    t.material = (uint32_t)(int32_t)(int16_t)in.material;
+    if (in.flags & 1u) { vset(t.n1, in.n); vset(t.n2, in.n + 3); vset(t.n3, in.n + 6); }
+    else {
+        v3 e2 = {t.p3[0] - t.p1[0], t.p3[1] - t.p1[1], t.p3[2] - t.p1[2]};
+        v3 e1 = {t.p2[0] - t.p1[0], t.p2[1] - t.p1[1], t.p2[2] - t.p1[2]};
+        v3 nn; vcross(nn, e2, e1); vnormalize(nn, nn);
+        vset(t.n1, nn); vset(t.n2, nn); vset(t.n3, nn);
+    }
+}
+
+// one 448-B PTri_AVX record from `count` consecutive 196-B PackagedTri records (Scene.h:154-173, XYZ.cpp:461-478)
+void fill_packet(uint8_t* pk, const uint8_t* tris196, int count, int32_t index) {
+    std::memset(pk, 0, 448);
+    for (int j = 0; j < count; j++) {
+        const uint8_t* t = tris196 + (size_t)j * 196;
+        std::memcpy(pk + 0 + 4 * j, t + 0, 4);    std::memcpy(pk + 32 + 4 * j, t + 4, 4);    std::memcpy(pk + 64 + 4 * j, t + 8, 4);     // p1
+        std::memcpy(pk + 96 + 4 * j, t + 24, 4);  std::memcpy(pk + 128 + 4 * j, t + 28, 4);  std::memcpy(pk + 160 + 4 * j, t + 32, 4);   // p1p2
+        std::memcpy(pk + 192 + 4 * j, t + 12, 4); std::memcpy(pk + 224 + 4 * j, t + 16, 4);  std::memcpy(pk + 256 + 4 * j, t + 20, 4);   // p1p3
+        std::memcpy(pk + 288 + 12 * j, t + 76, 12);                                                                                    // origin_offset
+        std::memcpy(pk + 384 + 4 * j, t + 60, 4);                                                                                      // material
+    }
+    const int8_t cnt = (int8_t)count;
+    std::memcpy(pk + 416, &index, 4); std::memcpy(pk + 420, &cnt, 1);
+}
+
 }  // namespace
 
 struct srx_package {
     std::vector<uint8_t> nodes, packets, tris;
+    std::vector<uint32_t> order;            // order[k] = index of the INPUT triangle that tri_data[k] was packed from
+    // the fast builder's arrays (malloc'd: pages first touched by the threads that fill them, no serial zero fill)
+    uint8_t* raw_packets = nullptr; uint8_t* raw_tris = nullptr; uint32_t* raw_order = nullptr;
     uint32_t n_nodes = 0, n_packets = 0, n_tris = 0;
+    ~srx_package() { std::free(raw_packets); std::free(raw_tris); std::free(raw_order); }
+    srx_package() = default;
+    srx_package(const srx_package&) = delete;
+    srx_package& operator=(const srx_package&) = delete;
 };
 
 extern "C" int srx_package_create(const srx_tri* in, uint32_t n, srx_package** out) {
     if (!in || n == 0 || !out) { srx_set_error("srx_package_create: zero geometry (the reference asserts here, BVH.h:100)"); return 1; }
     try {
         std::vector<HTri> T(n);
-        for (uint32_t i = 0; i < n; i++) {                          // Tri ctor Primitives.h:238-252
-            HTri& t = T[i];
-            vset(t.p1, in[i].p); vset(t.p2, in[i].p + 3); vset(t.p3, in[i].p + 6);
-            t.uv1[0] = in[i].uv[0]; t.uv1[1] = in[i].uv[1]; t.uv2[0] = in[i].uv[2]; t.uv2[1] = in[i].uv[3];
-            t.uv3[0] = in[i].uv[4]; t.uv3[1] = in[i].uv[5];
-            for (int k = 0; k < 3; k++) t.mid[k] = (t.p1[k] + t.p2[k] + t.p3[k]) / 3;
-            v3 m; vmax(m, t.p2, t.p3); vmax(t.bmax, t.p1, m);
-            vmin(m, t.p2, t.p3); vmin(t.bmin, t.p1, m);
-            t.material = (uint32_t)(int32_t)(int16_t)in[i].material;
-            if (in[i].flags & 1u) { vset(t.n1, in[i].n); vset(t.n2, in[i].n + 3); vset(t.n3, in[i].n + 6); }
-            else {
-                v3 e2 = {t.p3[0] - t.p1[0], t.p3[1] - t.p1[1], t.p3[2] - t.p1[2]};
-                v3 e1 = {t.p2[0] - t.p1[0], t.p2[1] - t.p1[1], t.p2[2] - t.p1[2]};
-                v3 nn; vcross(nn, e2, e1); vnormalize(nn, nn);
-                vset(t.n1, nn); vset(t.n2, nn); vset(t.n3, nn);
-            }
-        }
+        for (uint32_t i = 0; i < n; i++) make_htri(in[i], T[i]);
         Builder B(T);
         std::vector<uint32_t> all(n);
         for (uint32_t i = 0; i < n; i++) all[i] = i;
@@ -408,6 +432,7 @@ extern "C" int srx_package_create(const srx_tri* in, uint32_t n, srx_package** o
                         for (uint32_t id : b.elements) {
                             P->tris.resize((size_t)(P->n_tris + 1) * 196);
                             pack_tri(T[id], P->tris.data() + (size_t)P->n_tris * 196);
+                            P->order.push_back(id);
                             P->n_tris++;
                         }
                     } else {
@@ -474,9 +499,9 @@ extern "C" int srx_package_get(const srx_package* p, const void** nodes, uint32_
     if (!p) { srx_set_error("srx_package_get: null package"); return 1; }
     if (nodes) *nodes = p->nodes.data();
     if (n_nodes) *n_nodes = p->n_nodes;
-    if (packets) *packets = p->packets.data();
+    if (packets) *packets = p->raw_packets ? p->raw_packets : p->packets.data();
     if (n_packets) *n_packets = p->n_packets;
-    if (tris) *tris = p->tris.data();
+    if (tris) *tris = p->raw_tris ? p->raw_tris : p->tris.data();
     if (n_tris) *n_tris = p->n_tris;
     return 0;
 }
@@ -534,5 +559,333 @@ extern "C" int srx_build_tables(float* arccos2048, float* pdf1m) {
             pdf1m[(size_t)ia * R + i] = (float)t_pos;
         }
     }
+    return 0;
+}
+
+// =====================================================================================================================
+// srx_package_create_fast — a DIFFERENT tree over the same triangles (second half): parallel binned
+// SAH (16 bins on the axis of the largest centroid extent, cost = area x packets), tight leaf boxes, greedy 8-wide
+// collapse. The reference's builder (BVH::construct / probe, BVH.h:98-180, :581-653) is single-threaded and sorts every
+// node three times; its numbering of tri_data is a by-product of that build, so a different tree numbers the triangles
+// differently: every package therefore carries `order` (tri_data index -> input triangle), through which hits of the two
+// trees are compared (srx_package_get_order). PackagedTri / PTri_AVX records per triangle are the same bytes in both.
+// What this tree does NOT reproduce (opt-in, not the parity path): the reference's origin-grown leaf boxes (quirk Q1;
+// leaves here are tight, so far fewer packets are tested) and the invisibility of exactly flat axis-aligned subtrees
+// (quirk Q3; flat boxes get a little thickness here).
+// =====================================================================================================================
+namespace {
+
+struct FBox {
+    float mn[3], mx[3];
+    void reset() { for (int a = 0; a < 3; a++) { mn[a] = 3.0e38f; mx[a] = -3.0e38f; } }
+    void grow(const float* lo, const float* hi) { for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], lo[a]); mx[a] = std::max(mx[a], hi[a]); } }
+    void grow(const FBox& b) { grow(b.mn, b.mx); }
+    float half_area() const { const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2]; return x * y + x * z + y * z; }
+};
+struct FNode { FBox box; int left = -1, right = -1; uint32_t first = 0, count = 0; int sub = -1; };   // leaf: left < 0; sub >= 0: root of subtree `sub`
+
+template <class F>
+void parallel_chunks(int threads, size_t n, F fn) {       // fn(chunk, begin, end)
+    if (threads <= 1 || n < 65536) { fn(0, (size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    const size_t per = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        const size_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
+        if (b < e) pool.emplace_back([=] { fn(t, b, e); });
+    }
+    for (auto& th : pool) th.join();
+}
+
+// what the tree build needs of a triangle, 32 bytes, moved around by the partitions (streaming access, no indirection)
+struct Prim { float mn[3], mx[3]; uint32_t id, pad; };
+
+struct FastBuilder {
+    Prim* P;          // the triangles, reordered in place into leaf order
+    Prim* tmp;        // scratch of the same size for the out-of-place partitions of the parallel top
+    int threads;
+    static constexpr int BINS = 16;
+    static float packets(uint32_t n) { return (float)((n + 7u) / 8u); }
+    struct Bins { FBox box[BINS]; uint32_t cnt[BINS]; void clear() { for (int k = 0; k < BINS; k++) { box[k].reset(); cnt[k] = 0; } } };
+
+    // Splits [lo, hi): returns mid and the children's boxes. par = every thread works on this one node.
+    size_t split(size_t lo, size_t hi, bool par, FBox& lbox, FBox& rbox) {
+        const size_t n = hi - lo;
+        const int nt = (par && n >= 65536) ? threads : 1;
+        // bounds of the box centres (twice the centre, to be exact: mn + mx)
+        FBox cbs[64];
+        for (int t = 0; t < nt; t++) cbs[t].reset();
+        parallel_chunks(nt, n, [&](int t, size_t b, size_t e) {
+            FBox c; c.reset();
+            for (size_t i = lo + b; i < lo + e; i++) { const Prim& p = P[i]; const float m[3] = {p.mn[0] + p.mx[0], p.mn[1] + p.mx[1], p.mn[2] + p.mx[2]}; c.grow(m, m); }
+            cbs[t] = c;
+        });
+        FBox cb; cb.reset();
+        for (int t = 0; t < nt; t++) if (cbs[t].mn[0] <= cbs[t].mx[0]) cb.grow(cbs[t]);
+        int axis = 0;
+        for (int a = 1; a < 3; a++) if (cb.mx[a] - cb.mn[a] > cb.mx[axis] - cb.mn[axis]) axis = a;
+        const float ext = cb.mx[axis] - cb.mn[axis];
+        if (ext > 0.0f && std::isfinite(ext)) {
+            const float scale = (float)BINS / ext, c0 = cb.mn[axis];
+            auto bin_of = [&](const Prim& p) { int b = (int)(((p.mn[axis] + p.mx[axis]) - c0) * scale); return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b); };
+            static thread_local std::vector<Bins> all;
+            if ((int)all.size() < nt) all.resize((size_t)nt);
+            Bins* const allp = all.data();
+            parallel_chunks(nt, n, [&, allp](int t, size_t b, size_t e) {
+                Bins bn; bn.clear();
+                for (size_t i = lo + b; i < lo + e; i++) { const Prim& p = P[i]; const int k = bin_of(p); bn.cnt[k]++; bn.box[k].grow(p.mn, p.mx); }
+                allp[t] = bn;
+            });
+            Bins bn = allp[0];
+            for (int t = 1; t < nt; t++) for (int k = 0; k < BINS; k++) if (allp[t].cnt[k]) { bn.cnt[k] += allp[t].cnt[k]; bn.box[k].grow(allp[t].box[k]); }
+            // sweep: cost of a plane after bin k = area(L) x packets(L) + area(R) x packets(R)
+            FBox rb[BINS]; uint32_t rc[BINS];
+            FBox acc; acc.reset(); uint32_t c = 0;
+            for (int k = BINS - 1; k > 0; k--) { if (bn.cnt[k]) acc.grow(bn.box[k]); c += bn.cnt[k]; rb[k] = acc; rc[k] = c; }
+            acc.reset(); c = 0;
+            float best = 3.0e38f; int best_k = -1; size_t n_left = 0;
+            for (int k = 0; k < BINS - 1; k++) {
+                if (bn.cnt[k]) acc.grow(bn.box[k]);
+                c += bn.cnt[k];
+                if (c == 0 || rc[k + 1] == 0) continue;
+                const float cost = acc.half_area() * packets(c) + rb[k + 1].half_area() * packets(rc[k + 1]);
+                if (cost < best) { best = cost; best_k = k; lbox = acc; rbox = rb[k + 1]; n_left = c; }
+            }
+            if (best_k >= 0) {
+                const int k0 = best_k;
+                if (nt == 1) {
+                    std::partition(P + lo, P + hi, [&](const Prim& p) { return bin_of(p) <= k0; });
+                } else {
+                    // out-of-place partition: every thread counts its chunk, then writes its lefts and rights where they belong
+                    size_t lefts[65] = {0};
+                    parallel_chunks(nt, n, [&](int t, size_t b, size_t e) { size_t l = 0; for (size_t i = lo + b; i < lo + e; i++) l += bin_of(P[i]) <= k0; lefts[t + 1] = l; });
+                    const size_t per = (n + nt - 1) / nt;
+                    size_t loff[64], roff[64], la = 0, ra = 0;
+                    for (int t = 0; t < nt; t++) {
+                        loff[t] = la; roff[t] = ra;
+                        const size_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
+                        la += lefts[t + 1]; ra += (e - b) - lefts[t + 1];
+                    }
+                    parallel_chunks(nt, n, [&](int t, size_t b, size_t e) {
+                        size_t l = lo + loff[t], r = lo + n_left + roff[t];
+                        for (size_t i = lo + b; i < lo + e; i++) { if (bin_of(P[i]) <= k0) tmp[l++] = P[i]; else tmp[r++] = P[i]; }
+                    });
+                    parallel_chunks(nt, n, [&](int, size_t b, size_t e) { std::memcpy(P + lo + b, tmp + lo + b, (e - b) * sizeof(Prim)); });
+                }
+                return lo + n_left;
+            }
+        }
+        // all centres in one place (or not finite): halves by position in the list
+        const size_t mid = lo + n / 2;
+        lbox.reset(); rbox.reset();
+        for (size_t i = lo; i < mid; i++) lbox.grow(P[i].mn, P[i].mx);
+        for (size_t i = mid; i < hi; i++) rbox.grow(P[i].mn, P[i].mx);
+        return mid;
+    }
+
+    // serial recursion below the parallel top; nodes appended to `out`, returns the subtree's root index in `out`
+    int build(size_t lo, size_t hi, const FBox& box, std::vector<FNode>& out) {
+        const int me = (int)out.size();
+        out.emplace_back();
+        out[me].box = box;
+        if (hi - lo <= 8) { out[me].first = (uint32_t)lo; out[me].count = (uint32_t)(hi - lo); return me; }
+        FBox lb, rb;
+        const size_t mid = split(lo, hi, false, lb, rb);
+        const int l = build(lo, mid, lb, out);
+        const int r = build(mid, hi, rb, out);
+        out[me].left = l; out[me].right = r;
+        return me;
+    }
+};
+
+}  // namespace
+
+extern "C" int srx_package_create_fast(const srx_tri* in, uint32_t n, srx_package** out) {
+    if (!in || n == 0 || !out) { srx_set_error("srx_package_create_fast: zero geometry"); return 1; }
+    Prim* prims = nullptr; Prim* scratch = nullptr;
+    srx_package* P = nullptr;
+    try {
+        int threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("SRX_BUILD_THREADS")) threads = std::max(1, std::min(64, std::atoi(e)));
+        const bool timing = std::getenv("SRX_BUILD_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        // malloc, not vectors: no serial zero fill of gigabytes; the pages are first touched by the threads that fill them
+        prims = (Prim*)std::malloc((size_t)n * sizeof(Prim)); scratch = (Prim*)std::malloc((size_t)n * sizeof(Prim));
+        if (!prims || !scratch) throw std::bad_alloc();
+        std::vector<FBox> parts((size_t)threads);
+        for (auto& p : parts) p.reset();
+        parallel_chunks(threads, n, [&](int t, size_t b, size_t e) {
+            FBox x; x.reset();
+            for (size_t i = b; i < e; i++) {
+                Prim& p = prims[i];
+                const float* v = in[i].p;
+                for (int a = 0; a < 3; a++) { p.mn[a] = std::min(v[a], std::min(v[3 + a], v[6 + a])); p.mx[a] = std::max(v[a], std::max(v[3 + a], v[6 + a])); }
+                p.id = (uint32_t)i; p.pad = 0;
+                x.grow(p.mn, p.mx);
+            }
+            parts[t] = x;
+        });
+        FBox root_box; root_box.reset();
+        for (auto& p : parts) if (p.mn[0] <= p.mx[0]) root_box.grow(p);
+        for (int a = 0; a < 3; a++) if (!std::isfinite(root_box.mn[a]) || !std::isfinite(root_box.mx[a])) throw std::runtime_error("a vertex coordinate is not finite");
+        FastBuilder B{prims, scratch, threads};
+        // ---- top of the tree: one node at a time with every thread on it, until the ranges are small enough to hand out
+        const size_t hand_out = std::max<size_t>(4096, (size_t)n / (size_t)(threads * 16));
+        std::vector<FNode> top;
+        struct Range { size_t lo, hi; int node; };
+        std::vector<Range> subtasks;
+        {
+            std::deque<Range> q;
+            top.emplace_back(); top[0].box = root_box;
+            q.push_back({0, n, 0});
+            while (!q.empty()) {
+                const Range r = q.front(); q.pop_front();
+                if (r.hi - r.lo <= hand_out) { subtasks.push_back(r); continue; }
+                FBox lb, rb;
+                const size_t mid = B.split(r.lo, r.hi, true, lb, rb);
+                const int l = (int)top.size(); top.emplace_back(); top[l].box = lb;
+                const int rr = (int)top.size(); top.emplace_back(); top[rr].box = rb;
+                top[r.node].left = l; top[r.node].right = rr;
+                q.push_back({r.lo, mid, l}); q.push_back({mid, r.hi, rr});
+            }
+        }
+        // ---- subtrees, one per task, by a crew of threads (largest first)
+        std::sort(subtasks.begin(), subtasks.end(), [](const Range& a, const Range& b) { return a.hi - a.lo > b.hi - b.lo; });
+        std::vector<std::vector<FNode>> subs(subtasks.size());
+        {
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                for (size_t k; (k = next.fetch_add(1)) < subtasks.size();) {
+                    subs[k].reserve((subtasks[k].hi - subtasks[k].lo) / 3 + 16);
+                    B.build(subtasks[k].lo, subtasks[k].hi, top[subtasks[k].node].box, subs[k]);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < threads; t++) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+        }
+        for (size_t k = 0; k < subtasks.size(); k++) top[subtasks[k].node].sub = (int)k;
+        std::free(scratch); scratch = nullptr;
+        const auto t1 = std::chrono::steady_clock::now();
+
+        // ---- greedy 8-wide collapse, breadth first (a child's index is larger than its parent's, the root is node 0)
+        struct Ref { int sub, node; };     // sub < 0: the top array
+        auto deref = [&](Ref r) -> const FNode& { return r.sub < 0 ? top[r.node] : subs[r.sub][r.node]; };
+        auto resolve = [&](Ref r) { while (r.sub < 0 && top[r.node].sub >= 0) r = Ref{top[r.node].sub, 0}; return r; };
+        auto kids = [&](Ref r, Ref& a, Ref& b) { const FNode& nd = deref(r); a = resolve(Ref{r.sub, nd.left}); b = resolve(Ref{r.sub, nd.right}); };
+        struct Wide { Ref child[8]; int n; int parent, slot; };
+        std::vector<Wide> wide;
+        struct Leaf { uint32_t first, count; };
+        std::vector<Leaf> leaves;              // in emission order: leaf l -> packet l, tri_data offset = prefix sum of counts
+        std::vector<uint32_t> leaf_of_slot;    // per wide node x 8: leaf id or ~0u
+        wide.reserve((size_t)n / 24 + 16); leaves.reserve((size_t)n / 5 + 16); leaf_of_slot.reserve((size_t)n / 3 + 128);
+        {
+            std::deque<std::pair<Ref, std::pair<int, int>>> q;
+            q.push_back({resolve(Ref{-1, 0}), {-1, -1}});
+            while (!q.empty()) {
+                const auto item = q.front(); q.pop_front();
+                Wide w; w.n = 0; w.parent = item.second.first; w.slot = item.second.second;
+                const Ref root = item.first;
+                if (deref(root).left < 0) w.child[w.n++] = root;          // a tree that is one leaf
+                else { Ref a, b; kids(root, a, b); w.child[w.n++] = a; w.child[w.n++] = b; }
+                while (w.n < 8) {
+                    int pick = -1; float best = -1.0f;
+                    for (int k = 0; k < w.n; k++) {
+                        const FNode& c = deref(w.child[k]);
+                        if (c.left >= 0 && c.box.half_area() > best) { best = c.box.half_area(); pick = k; }
+                    }
+                    if (pick < 0) break;
+                    Ref a, b; kids(w.child[pick], a, b);
+                    w.child[pick] = a; w.child[w.n++] = b;
+                }
+                const int self = (int)wide.size();
+                wide.push_back(w);
+                leaf_of_slot.resize((size_t)(self + 1) * 8, ~0u);
+                for (int k = 0; k < w.n; k++) {
+                    const FNode& c = deref(w.child[k]);
+                    if (c.left < 0) { leaf_of_slot[(size_t)self * 8 + k] = (uint32_t)leaves.size(); leaves.push_back({c.first, c.count}); }
+                    else q.push_back({w.child[k], {self, k}});
+                }
+            }
+        }
+        std::vector<uint32_t> child_index((size_t)wide.size() * 8, 0);
+        for (size_t i = 1; i < wide.size(); i++) child_index[(size_t)wide[i].parent * 8 + wide[i].slot] = (uint32_t)i;
+        std::vector<uint32_t> tri0(leaves.size() + 1, 0);
+        for (size_t l = 0; l < leaves.size(); l++) tri0[l + 1] = tri0[l] + leaves[l].count;
+        const auto t2 = std::chrono::steady_clock::now();
+
+        // ---- records, in parallel: PackagedTri + one PTri_AVX per leaf, then the BVH_AVX nodes
+        P = new srx_package();
+        P->n_tris = n; P->n_packets = (uint32_t)leaves.size(); P->n_nodes = (uint32_t)wide.size();
+        P->raw_tris = (uint8_t*)std::malloc((size_t)n * 196); P->raw_packets = (uint8_t*)std::malloc(std::max<size_t>(1, leaves.size()) * 448);
+        P->raw_order = (uint32_t*)std::malloc((size_t)n * sizeof(uint32_t));
+        if (!P->raw_tris || !P->raw_packets || !P->raw_order) throw std::bad_alloc();
+        P->nodes.assign((size_t)wide.size() * 288, 0);
+        std::vector<FBox> leaf_box(leaves.size());
+        const float thick = 1e-6f * std::max(std::max(root_box.mx[0] - root_box.mn[0], root_box.mx[1] - root_box.mn[1]),
+                                              std::max(root_box.mx[2] - root_box.mn[2], 1e-3f));
+        auto thicken = [&](FBox b) {          // quirk Q3: a box with tmin == tmax is a miss (BVH.h:973-977): no exactly flat boxes here
+            for (int a = 0; a < 3; a++) if (!(b.mx[a] - b.mn[a] > 0.0f)) { const float d = std::max(thick, std::fabs(b.mx[a]) * 1e-6f); b.mn[a] -= d; b.mx[a] += d; }
+            return b;
+        };
+        {
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                HTri t;
+                for (size_t base; (base = next.fetch_add(2048)) < leaves.size();)
+                    for (size_t l = base; l < std::min(leaves.size(), base + 2048); l++) {
+                        FBox b; b.reset();
+                        for (uint32_t j = 0; j < leaves[l].count; j++) {
+                            const Prim& pr = prims[leaves[l].first + j];
+                            make_htri(in[pr.id], t);
+                            pack_tri(t, P->raw_tris + (size_t)(tri0[l] + j) * 196);
+                            P->raw_order[tri0[l] + j] = pr.id;
+                            b.grow(pr.mn, pr.mx);
+                        }
+                        fill_packet(P->raw_packets + l * 448, P->raw_tris + (size_t)tri0[l] * 196, (int)leaves[l].count, (int32_t)tri0[l]);
+                        leaf_box[l] = b;
+                    }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < threads; t++) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+        }
+        parallel_chunks(threads, wide.size(), [&](int, size_t b, size_t e) {
+            for (size_t i = b; i < e; i++) {
+                uint8_t* rec = P->nodes.data() + i * 288;
+                for (int k = 0; k < wide[i].n; k++) {
+                    const uint32_t leaf = leaf_of_slot[i * 8 + k];
+                    const FBox bx = thicken(leaf != ~0u ? leaf_box[leaf] : deref(wide[i].child[k]).box);
+                    std::memcpy(rec + 0 + 4 * k, &bx.mx[0], 4); std::memcpy(rec + 32 + 4 * k, &bx.mx[1], 4); std::memcpy(rec + 64 + 4 * k, &bx.mx[2], 4);
+                    std::memcpy(rec + 96 + 4 * k, &bx.mn[0], 4); std::memcpy(rec + 128 + 4 * k, &bx.mn[1], 4); std::memcpy(rec + 160 + 4 * k, &bx.mn[2], 4);
+                    const uint32_t leaf_size = leaf != ~0u ? 1u : 0u, index = leaf != ~0u ? leaf : child_index[i * 8 + k];
+                    std::memcpy(rec + 192 + 4 * k, &leaf_size, 4); std::memcpy(rec + 224 + 4 * k, &index, 4);
+                }
+                const int32_t parent = wide[i].parent, self = (int32_t)i;
+                std::memcpy(rec + 256, &parent, 4); std::memcpy(rec + 260, &self, 4);
+            }
+        });
+        std::free(prims); prims = nullptr;
+        if (timing) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto s = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+            std::fprintf(stderr, "srx_package_create_fast: %u tris, %d threads: tree %.3f s (%zu top nodes, %zu subtrees), collapse %.3f s, records %.3f s: %zu nodes, %zu packets\n",
+                         n, threads, s(t0, t1), top.size(), subs.size(), s(t1, t2), s(t2, t3), wide.size(), leaves.size());
+        }
+        *out = P;
+        return 0;
+    } catch (const std::exception& e) {
+        std::free(prims); std::free(scratch);
+        delete P;
+        srx_set_error(std::string("srx_package_create_fast: ") + e.what());
+        return 1;
+    }
+}
+
+extern "C" int srx_package_get_order(const srx_package* p, const uint32_t** order, uint32_t* n) {
+    if (!p || !order) { srx_set_error("srx_package_get_order: null argument"); return 1; }
+    *order = p->raw_order ? p->raw_order : p->order.data();
+    if (n) *n = p->n_tris;
     return 0;
 }

@@ -58,12 +58,16 @@ class PackagedScene:
         self.tables = tables        # optional (arccos2048, pdf1m); built by the library when None
 
 
-def package(desc, tables=None) -> PackagedScene:
-    """`Scene::package()` (Scene.h:90-179) through `srx_package_create`."""
+def package(desc, tables=None, fast=False) -> PackagedScene:
+    """`Scene::package()` (Scene.h:90-179) through `srx_package_create`; fast=True: the opt-in builder of a different tree
+    (`srx_package_create_fast`: not the reference's triangle numbering). `.order[k]` = input triangle of tri_data[k]."""
     L = _lib.lib()
     tris = np.ascontiguousarray(desc.tris)
     pkg = C.c_void_p()
-    check(L.srx_package_create(_p(tris), C.c_uint32(len(tris)), C.byref(pkg)), "srx_package_create")
+    if fast:
+        check(L.srx_package_create_fast(_p(tris), C.c_uint32(len(tris)), C.byref(pkg)), "srx_package_create_fast")
+    else:
+        check(L.srx_package_create(_p(tris), C.c_uint32(len(tris)), C.byref(pkg)), "srx_package_create")
     try:
         pn, pp, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
         nn, npk, nt = C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -75,10 +79,15 @@ def package(desc, tables=None) -> PackagedScene:
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * sz,)).copy().reshape(n, sz)
 
         nodes, packets, ptris = grab(pn, nn.value, 288), grab(pp, npk.value, 448), grab(pt, nt.value, 196)
+        po, no = C.POINTER(C.c_uint32)(), C.c_uint32()
+        check(L.srx_package_get_order(pkg, C.byref(po), C.byref(no)), "srx_package_get_order")
+        order = np.ctypeslib.as_array(po, shape=(no.value,)).copy() if no.value else np.zeros(0, np.uint32)
     finally:
         L.srx_package_destroy(pkg)
-    return PackagedScene(nodes, packets, ptris, desc.materials, desc.textures, desc.suns, desc.max_generations,
-                         desc.monte_carlo_max, desc.monte_carlo_modifier, tables)
+    PS = PackagedScene(nodes, packets, ptris, desc.materials, desc.textures, desc.suns, desc.max_generations,
+                       desc.monte_carlo_max, desc.monte_carlo_modifier, tables)
+    PS.order = order
+    return PS
 
 
 def build_tables():
