@@ -308,7 +308,7 @@ int srx_write_png(const char* path, const uint8_t* d_rgba8, int32_t res_x, int32
  * 438-782) and the flattening the reference applies before Scene::package (Object::fetchData, Primitives.h:423-434):
  * a binary glTF (.glb) becomes world-space srx_tri records (in the order Scene::package would collect them), the
  * material table (the file's materials + the reference's "SR default material" last), textures as the reference
- * stores them (Texture.h, 3 bytes per texel; embedded 8-bit PNG images only), sun lights and the first camera
+ * stores them (Texture.h, 3 bytes per texel; embedded 8-bit PNG and baseline JPEG images), sun lights and the first camera
  * (res_x, res_y, subdiv are left 0 for the caller). Axis conventions, factors and quirks: see csrc/srx_gltf.cpp.
  * Host-only; the arrays belong to the handle. */
 typedef struct srx_gltf srx_gltf;
@@ -316,6 +316,12 @@ int srx_gltf_load(const char* path, srx_gltf** out);
 void srx_gltf_destroy(srx_gltf* g);
 int srx_gltf_get(const srx_gltf* g, const srx_tri** tris, uint32_t* n_tris, const srx_material** materials, uint32_t* n_materials,
                  const srx_texture** textures, uint32_t* n_textures, const srx_sun** suns, uint32_t* n_suns, srx_camera* camera);
+/* The image decoder the loader uses, on its own: replaces stbi_load_from_memory(..., req_comp = 4) as tinygltf's
+ * LoadImageData calls it for every embedded image (FileLoading.h:438 goes through tinygltf::TinyGLTF::LoadBinaryFromFile;
+ * stb_image.h:1399, 3865-4026 for JPEG). 8-bit non-interlaced PNG and baseline / extended-sequential Huffman JPEG
+ * (1 or 3 components, any sampling factors that divide the largest); JPEG bytes equal stb_image's. Writes width and
+ * height; when rgba is not NULL also width * height * 4 bytes (refused if capacity is smaller). Host-only. */
+int srx_image_decode(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint8_t* rgba, size_t capacity);
 
 /* ---- multi-GPU exchange: one process per GPU, scene replicated, tile rows dealt round-robin
  * (srx_trace_pass_interleaved), nothing exchanged on the sample path. What the reference's worker threads hand over in

@@ -88,6 +88,19 @@ def swz(v):
 
 
 # ---- images and textures
+# JPEG pixels are not restated here: tests hand in what the reference's own stb_image gives for the file (committed under
+# tests/golden/jpeg_cases.npz, or oracle/_ref/libref_stb.so) through this hook: bytes -> (h, w, 4) uint8
+jpeg_decoder = None
+
+
+def decode_image(data):
+    if data[:2] == b"\xff\xd8":
+        if jpeg_decoder is None:
+            raise ValueError("JPEG image and no sro_gltf.jpeg_decoder set")
+        return jpeg_decoder(bytes(data))
+    return decode_png(data)
+
+
 def decode_png(data):
     if data[:8] != b"\x89PNG\r\n\x1a\n":
         raise ValueError("not a PNG")
@@ -214,7 +227,7 @@ def load(path):
             im = js["images"][js["textures"][t_index]["source"]]
             bv = js["bufferViews"][im["bufferView"]]
             data = binc[bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]]
-            base_cache[key] = load_texture(decode_png(data), srgb, with_scale, scale_v)
+            base_cache[key] = load_texture(decode_image(data), srgb, with_scale, scale_v)
         return base_cache[key]
 
     textures, materials, uv_map = [], [], []

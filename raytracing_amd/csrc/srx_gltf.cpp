@@ -5,8 +5,8 @@
 // 423-434) with Object::compile_scale (:462-471) and Transformation::collpase (Transformation.h:28-57).
 //
 // The reference reads the file with tinygltf (a third-party header, not restated: this file has its own JSON and GLB
-// reader) and decodes embedded images with stb_image; here images must be 8-bit non-interlaced PNG (own inflate), any
-// other image fails loudly. Reference behaviour kept on purpose (each is what the author's scenes were exported for):
+// reader) and decodes embedded images with stb_image; here images are 8-bit non-interlaced PNG (own inflate) or baseline
+// JPEG (own decoder following stb_image's arithmetic, checked against it), any other image fails loudly. Reference behaviour kept on purpose (each is what the author's scenes were exported for):
 //  * axis swizzle (x, -z, y) for positions, normals and translations, (x, z, y) for scales, (x, -z, y, w) for
 //    rotations (:450-452); uv -> (u, 1 - v) (:658-660); emissive x 25 (:473); sun emission = color * intensity / 50000
 //    (:731), sun direction = (0, -1, 0) rotated (:726-727);
@@ -299,7 +299,7 @@ std::vector<uint8_t> inflate_zlib(const uint8_t* d, size_t n, size_t max_out) {
 struct Image { int w = 0, h = 0, comp = 0; std::vector<uint8_t> px; };   // comp 3 or 4, rows top to bottom (stb_image layout)
 Image decode_png(const uint8_t* d, size_t n) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    if (n < 8 || std::memcmp(d, sig, 8)) fail("image is not a PNG (only 8-bit non-interlaced PNG images are decoded; the reference uses stb_image)");
+    if (n < 8 || std::memcmp(d, sig, 8)) fail("image is neither a PNG nor a JPEG (8-bit non-interlaced PNG and baseline JPEG images are decoded; the reference uses stb_image)");
     Image im; int ctype = -1;
     std::vector<uint8_t> z, plte;
     for (size_t at = 8; at + 12 <= n;) {
@@ -359,6 +359,415 @@ Image decode_png(const uint8_t* d, size_t n) {
         im.px[4 * i] = r; im.px[4 * i + 1] = g; im.px[4 * i + 2] = b; im.px[4 * i + 3] = a;
     }
     return im;
+}
+
+// ---------------------------------------------------------------- JPEG (baseline / extended sequential Huffman, 8 bits)
+// The reference decodes images with stb_image 2.28 (through tinygltf, 4 components requested). Texel values feed the
+// shading, so the decoder follows stb_image's arithmetic step for step: the integer slow IDCT of jidctint with 12-bit
+// constants and stb's two extra bits between the passes, its chroma upsampling filters (h2v1: 3/4 + 1/4 across, h1v2:
+// the same down, h2v2: both, anything else: nearest) and its 20-bit fixed-point YCbCr -> RGB. tests/test_gltf_cpu.py
+// compares the decoded bytes with stb_image's own (oracle/_ref/ref_stb_probe, built from the reference's vendored header).
+// Progressive and arithmetic-coded files, 12-bit samples and CMYK fail loudly.
+struct JpegHuff { uint8_t size[257]; uint16_t code[256]; uint8_t values[256]; int maxcode[18]; int delta[17]; int n = 0; bool set = false; };
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dc_pred = 0; int x = 0, y = 0, w2 = 0, h2 = 0; std::vector<uint8_t> data; };
+struct JpegDec {
+    const uint8_t* d; size_t n, pos = 0;
+    uint32_t code_buffer = 0; int code_bits = 0; int marker = -1; bool nomore = false;
+    JpegHuff hdc[4], hac[4];
+    uint16_t dequant[4][64];
+    JpegComp comp[4];
+    int ncomp = 0, img_x = 0, img_y = 0, h_max = 1, v_max = 1, mcu_x = 0, mcu_y = 0, mcu_w = 0, mcu_h = 0;
+    int restart_interval = 0, todo = 0;
+    int scan_n = 0, order[4];
+    bool jfif = false; int app14 = -1; int rgb = 0;
+
+    int get8() { return pos < n ? d[pos++] : 0; }
+    int get16() { const int a = get8(); return (a << 8) | get8(); }
+    void build(JpegHuff& h, const int* count) {                      // ITU T.81 Annex C, as every decoder does
+        int k = 0;
+        for (int i = 0; i < 16; i++) for (int j = 0; j < count[i]; j++) { h.size[k++] = (uint8_t)(i + 1); if (k >= 257) fail("JPEG: bad code lengths"); }
+        h.size[k] = 0; h.n = k;
+        int code = 0; k = 0;
+        for (int j = 1; j <= 16; j++) {
+            h.delta[j] = k - code;
+            if (h.size[k] == j) {
+                while (h.size[k] == j) h.code[k++] = (uint16_t)(code++);
+                if (code - 1 >= (1 << j)) fail("JPEG: bad code lengths");
+            }
+            h.maxcode[j] = code << (16 - j);
+            code <<= 1;
+        }
+        h.maxcode[17] = 0x7fffffff;
+        h.set = true;
+    }
+    void grow() {                                                     // bytes into the bit buffer; a marker ends the entropy-coded data
+        do {
+            unsigned b = nomore ? 0 : (unsigned)get8();
+            if (b == 0xff) {
+                int c = get8();
+                while (c == 0xff) c = get8();
+                if (c != 0) { marker = c; nomore = true; return; }
+            }
+            code_buffer |= b << (24 - code_bits);
+            code_bits += 8;
+        } while (code_bits <= 24);
+    }
+    int huff(const JpegHuff& h) {
+        if (code_bits < 16) grow();
+        const unsigned temp = code_buffer >> 16;
+        int k = 1;
+        while (k <= 16 && (int)temp >= h.maxcode[k]) k++;
+        if (k == 17) { code_bits -= 16; fail("JPEG: bad huffman code"); }
+        if (k > code_bits) fail("JPEG: bad huffman code");
+        const int c = (int)((code_buffer >> (32 - k)) & ((1u << k) - 1u)) + h.delta[k];
+        if (c < 0 || c >= h.n) fail("JPEG: bad huffman code");
+        code_bits -= k; code_buffer <<= k;
+        return h.values[c];
+    }
+    int extend_receive(int nb) {                                      // T.81 F.2.2.1: nb bits, sign-extended
+        if (nb == 0) return 0;
+        if (code_bits < nb) grow();
+        if (code_bits < nb) return 0;
+        const unsigned v = code_buffer >> (32 - nb);
+        code_buffer <<= nb; code_bits -= nb;
+        return (int)v < (1 << (nb - 1)) ? (int)v - (1 << nb) + 1 : (int)v;
+    }
+    void decode_block(short data[64], JpegComp& c) {
+        static const uint8_t dezigzag[64 + 15] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+            63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+        const uint16_t* dq = dequant[c.tq];
+        const int t = huff(hdc[c.hd]);
+        if (t > 15) fail("JPEG: bad DC code");
+        std::memset(data, 0, 64 * sizeof(short));
+        const int diff = t ? extend_receive(t) : 0;
+        const int dc = (int)((uint32_t)c.dc_pred + (uint32_t)diff);
+        c.dc_pred = dc;
+        data[0] = (short)((uint32_t)dc * dq[0]);
+        for (int k = 1; k < 64;) {
+            const int rs = huff(hac[c.ha]);
+            const int sz = rs & 15, r = rs >> 4;
+            if (sz == 0) {
+                if (rs != 0xf0) break;                                // end of block
+                k += 16;
+            } else {
+                k += r;
+                if (k > 63) fail("JPEG: coefficient index out of range");
+                const int zig = dezigzag[k++];
+                data[zig] = (short)((uint32_t)extend_receive(sz) * dq[zig]);
+            }
+        }
+    }
+    static uint8_t clamp8(int x) { return (unsigned)x > 255 ? (x < 0 ? 0 : 255) : (uint8_t)x; }
+    // jidctint's slow integer IDCT with 12-bit constants, two extra bits kept between the passes (stb_image's form of it)
+    static void idct(uint8_t* out, int stride, const short data[64]) {
+        auto f2f = [](double x) { return (int)(x * 4096 + 0.5); };
+        static const int c0541 = f2f(0.5411961f), c1847 = f2f(-1.847759065f), c0765 = f2f(0.765366865f), c1175 = f2f(1.175875602f),
+                         c0298 = f2f(0.298631336f), c2053 = f2f(2.053119869f), c3072 = f2f(3.072711026f), c1501 = f2f(1.501321110f),
+                         c0899 = f2f(-0.899976223f), c2562 = f2f(-2.562915447f), c1961 = f2f(-1.961570560f), c0390 = f2f(-0.390180644f);
+        // 32-bit wrap-around arithmetic (unsigned) so that damaged files cannot overflow a signed int; for valid data it is
+        // the same as stb_image's int arithmetic
+        typedef uint32_t U;
+        auto pass = [&](int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, U& x0, U& x1, U& x2, U& x3, U& t0, U& t1, U& t2, U& t3) {
+            U p2 = (U)s2, p3 = (U)s6;
+            U p1 = (p2 + p3) * (U)c0541;
+            t2 = p1 + p3 * (U)c1847; t3 = p1 + p2 * (U)c0765;
+            p2 = (U)s0; p3 = (U)s4;
+            t0 = (p2 + p3) * 4096u; t1 = (p2 - p3) * 4096u;
+            x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;
+            t0 = (U)s7; t1 = (U)s5; t2 = (U)s3; t3 = (U)s1;
+            p3 = t0 + t2; U p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
+            const U p5 = (p3 + p4) * (U)c1175;
+            t0 = t0 * (U)c0298; t1 = t1 * (U)c2053; t2 = t2 * (U)c3072; t3 = t3 * (U)c1501;
+            p1 = p5 + p1 * (U)c0899; p2 = p5 + p2 * (U)c2562; p3 = p3 * (U)c1961; p4 = p4 * (U)c0390;
+            t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+        };
+        auto sar = [](U x, int k) { return (int)x >> k; };
+        int val[64];
+        for (int i = 0; i < 8; i++) {
+            const short* dd = data + i; int* v = val + i;
+            if (dd[8] == 0 && dd[16] == 0 && dd[24] == 0 && dd[32] == 0 && dd[40] == 0 && dd[48] == 0 && dd[56] == 0) {
+                const int dcterm = dd[0] * 4;                         // a short times 4: no overflow
+                v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
+            } else {
+                U x0, x1, x2, x3, t0, t1, t2, t3;
+                pass(dd[0], dd[8], dd[16], dd[24], dd[32], dd[40], dd[48], dd[56], x0, x1, x2, x3, t0, t1, t2, t3);
+                x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+                v[0] = sar(x0 + t3, 10); v[56] = sar(x0 - t3, 10); v[8] = sar(x1 + t2, 10); v[48] = sar(x1 - t2, 10);
+                v[16] = sar(x2 + t1, 10); v[40] = sar(x2 - t1, 10); v[24] = sar(x3 + t0, 10); v[32] = sar(x3 - t0, 10);
+            }
+        }
+        for (int i = 0; i < 8; i++) {
+            const int* v = val + 8 * i; uint8_t* o = out + (size_t)stride * i;
+            U x0, x1, x2, x3, t0, t1, t2, t3;
+            pass(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], x0, x1, x2, x3, t0, t1, t2, t3);
+            const U bias = 65536u + (128u << 17);
+            x0 += bias; x1 += bias; x2 += bias; x3 += bias;
+            o[0] = clamp8(sar(x0 + t3, 17)); o[7] = clamp8(sar(x0 - t3, 17)); o[1] = clamp8(sar(x1 + t2, 17)); o[6] = clamp8(sar(x1 - t2, 17));
+            o[2] = clamp8(sar(x2 + t1, 17)); o[5] = clamp8(sar(x2 - t1, 17)); o[3] = clamp8(sar(x3 + t0, 17)); o[4] = clamp8(sar(x3 - t0, 17));
+        }
+    }
+    void reset_entropy() {
+        code_bits = 0; code_buffer = 0; nomore = false; marker = -1;
+        for (int i = 0; i < 4; i++) comp[i].dc_pred = 0;
+        todo = restart_interval ? restart_interval : 0x7fffffff;
+    }
+    void scan() {
+        reset_entropy();
+        short data[64];
+        auto restart = [&]() {                                        // after every restart interval: an RSTn marker, then a fresh decoder state
+            if (--todo <= 0) {
+                if (code_bits < 24) grow();
+                if (!(marker >= 0xd0 && marker <= 0xd7)) return false;
+                reset_entropy();
+            }
+            return true;
+        };
+        if (scan_n == 1) {                                            // one component: its own block grid, no MCU padding
+            JpegComp& c = comp[order[0]];
+            const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+            for (int j = 0; j < h; j++)
+                for (int i = 0; i < w; i++) {
+                    if (!hdc[c.hd].set || !hac[c.ha].set) fail("JPEG: scan uses a Huffman table that was not defined");
+                    decode_block(data, c);
+                    idct(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, data);
+                    if (!restart()) return;
+                }
+        } else {
+            for (int j = 0; j < mcu_y; j++)
+                for (int i = 0; i < mcu_x; i++) {
+                    for (int k = 0; k < scan_n; k++) {
+                        JpegComp& c = comp[order[k]];
+                        if (!hdc[c.hd].set || !hac[c.ha].set) fail("JPEG: scan uses a Huffman table that was not defined");
+                        for (int y = 0; y < c.v; y++)
+                            for (int x = 0; x < c.h; x++) {
+                                const int x2 = (i * c.h + x) * 8, y2 = (j * c.v + y) * 8;
+                                decode_block(data, c);
+                                idct(c.data.data() + (size_t)c.w2 * y2 + x2, c.w2, data);
+                            }
+                    }
+                    if (!restart()) return;
+                }
+        }
+    }
+    void frame_header(int m) {
+        if (m == 0xc2) fail("JPEG: progressive files are not decoded (baseline only); re-export the texture as baseline JPEG or PNG");
+        const int lf = get16();
+        if (lf < 11) fail("JPEG: bad SOF length");
+        if (get8() != 8) fail("JPEG: only 8-bit samples are decoded");
+        img_y = get16(); img_x = get16();
+        if (img_x <= 0 || img_y <= 0) fail("JPEG: bad size");
+        if ((uint64_t)img_x * (uint64_t)img_y > (1ull << 28)) fail("JPEG: image larger than 2^28 pixels");
+        ncomp = get8();
+        if (ncomp == 4) fail("JPEG: CMYK / 4-component files are not decoded");
+        if (ncomp != 1 && ncomp != 3) fail("JPEG: bad component count");
+        if (lf != 8 + 3 * ncomp) fail("JPEG: bad SOF length");
+        rgb = 0;
+        for (int i = 0; i < ncomp; i++) {
+            static const uint8_t rgbid[3] = {'R', 'G', 'B'};
+            comp[i].id = get8();
+            if (ncomp == 3 && comp[i].id == rgbid[i]) rgb++;
+            const int q = get8();
+            comp[i].h = q >> 4; comp[i].v = q & 15;
+            if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4) fail("JPEG: bad sampling factors");
+            comp[i].tq = get8();
+            if (comp[i].tq > 3) fail("JPEG: bad quantisation table index");
+        }
+        h_max = v_max = 1;
+        for (int i = 0; i < ncomp; i++) { h_max = std::max(h_max, comp[i].h); v_max = std::max(v_max, comp[i].v); }
+        for (int i = 0; i < ncomp; i++) if (h_max % comp[i].h || v_max % comp[i].v) fail("JPEG: sampling factors that do not divide the largest are not decoded");
+        mcu_w = h_max * 8; mcu_h = v_max * 8;
+        mcu_x = (img_x + mcu_w - 1) / mcu_w; mcu_y = (img_y + mcu_h - 1) / mcu_h;
+        for (int i = 0; i < ncomp; i++) {
+            comp[i].x = (img_x * comp[i].h + h_max - 1) / h_max;
+            comp[i].y = (img_y * comp[i].v + v_max - 1) / v_max;
+            comp[i].w2 = mcu_x * comp[i].h * 8; comp[i].h2 = mcu_y * comp[i].v * 8;
+            comp[i].data.assign((size_t)comp[i].w2 * comp[i].h2 + 15, 0);
+        }
+    }
+    void scan_header() {
+        const int ls = get16();
+        scan_n = get8();
+        if (scan_n < 1 || scan_n > ncomp) fail("JPEG: bad SOS component count");
+        if (ls != 6 + 2 * scan_n) fail("JPEG: bad SOS length");
+        for (int i = 0; i < scan_n; i++) {
+            const int id = get8(), q = get8();
+            int which = 0;
+            for (; which < ncomp; which++) if (comp[which].id == id) break;
+            if (which == ncomp) fail("JPEG: scan names a component the frame does not have");
+            comp[which].hd = q >> 4; comp[which].ha = q & 15;
+            if (comp[which].hd > 3 || comp[which].ha > 3) fail("JPEG: bad Huffman table index");
+            order[i] = which;
+        }
+        const int ss = get8(); get8(); const int a = get8();
+        if (ss != 0 || a != 0) fail("JPEG: not a baseline scan");
+    }
+    void marker_segment(int m) {
+        if (m == 0xdd) { if (get16() != 4) fail("JPEG: bad DRI length"); restart_interval = get16(); return; }
+        if (m == 0xdb) {                                              // quantisation tables, stored de-zigzagged
+            static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+            int l = get16() - 2;
+            while (l > 0) {
+                const int q = get8(), p = q >> 4, t = q & 15;
+                if ((p != 0 && p != 1) || t > 3) fail("JPEG: bad DQT");
+                for (int i = 0; i < 64; i++) dequant[t][zz[i]] = (uint16_t)(p ? get16() : get8());
+                l -= p ? 129 : 65;
+            }
+            if (l != 0) fail("JPEG: bad DQT length");
+            return;
+        }
+        if (m == 0xc4) {                                              // Huffman tables
+            int l = get16() - 2;
+            while (l > 0) {
+                const int q = get8(), tc = q >> 4, th = q & 15;
+                if (tc > 1 || th > 3) fail("JPEG: bad DHT");
+                int count[16], total = 0;
+                for (int i = 0; i < 16; i++) { count[i] = get8(); total += count[i]; }
+                if (total > 256) fail("JPEG: bad DHT");
+                JpegHuff& h = tc ? hac[th] : hdc[th];
+                build(h, count);
+                for (int i = 0; i < total; i++) h.values[i] = (uint8_t)get8();
+                l -= 17 + total;
+            }
+            if (l != 0) fail("JPEG: bad DHT length");
+            return;
+        }
+        if ((m >= 0xe0 && m <= 0xef) || m == 0xfe) {                  // APPn / COM: JFIF and Adobe say how the components are to be read
+            int l = get16();
+            if (l < 2) fail("JPEG: bad segment length");
+            l -= 2;
+            if (m == 0xe0 && l >= 5) {
+                static const char tag[5] = {'J', 'F', 'I', 'F', 0};
+                bool ok = true;
+                for (int i = 0; i < 5; i++) if (get8() != (uint8_t)tag[i]) ok = false;
+                l -= 5;
+                if (ok) jfif = true;
+            } else if (m == 0xee && l >= 12) {
+                static const char tag[6] = {'A', 'd', 'o', 'b', 'e', 0};
+                bool ok = true;
+                for (int i = 0; i < 6; i++) if (get8() != (uint8_t)tag[i]) ok = false;
+                l -= 6;
+                if (ok) { get8(); get16(); get16(); app14 = get8(); l -= 6; }
+            }
+            if (pos + (size_t)l > n) fail("JPEG: segment cut off");
+            pos += (size_t)l;
+            return;
+        }
+        fail("JPEG: unknown marker");
+    }
+    int next_marker() {
+        if (marker >= 0) { const int m = marker; marker = -1; return m; }
+        int x = get8();
+        if (x != 0xff) return -1;
+        while (x == 0xff) x = get8();
+        return x;
+    }
+};
+
+Image decode_jpeg(const uint8_t* d, size_t n) {
+    std::unique_ptr<JpegDec> zp(new JpegDec{d, n});
+    JpegDec& z = *zp;
+    std::memset(z.dequant, 0, sizeof(z.dequant));
+    if (z.get8() != 0xff || z.get8() != 0xd8) fail("JPEG: no SOI");
+    int m = z.next_marker();
+    while (!(m == 0xc0 || m == 0xc1 || m == 0xc2)) {
+        if (m < 0 || z.pos >= n) fail("JPEG: no frame header");
+        if (m == 0xc9 || m == 0xca || m == 0xcb || m == 0xc3) fail("JPEG: arithmetic-coded and lossless files are not decoded");
+        z.marker_segment(m);
+        m = z.next_marker();
+    }
+    z.frame_header(m);
+    bool seen_scan = false;
+    for (m = z.next_marker(); m != 0xd9; m = z.next_marker()) {
+        if (m == 0xda) {
+            z.scan_header();
+            z.scan();
+            seen_scan = true;
+            if (z.marker < 0) {                                       // skip whatever follows the entropy-coded data up to the next marker
+                while (z.pos < n) { if (z.get8() == 0xff) { const int c = z.get8(); if (c != 0 && c != 0xff) { z.marker = c; break; } } }
+                if (z.marker < 0) break;
+            }
+        } else if (m == 0xdc) { z.get16(); z.get16(); }               // DNL: the height was in the frame header
+        else if (m < 0) { if (z.pos >= n) break; fail("JPEG: data where a marker should be"); }
+        else z.marker_segment(m);
+    }
+    if (!seen_scan) fail("JPEG: no scan");
+    // ---- upsample and convert, row by row (stb_image's load_jpeg_image with 4 components requested)
+    Image im; im.w = z.img_x; im.h = z.img_y; im.comp = 4;
+    im.px.resize((size_t)im.w * im.h * 4);
+    const bool is_rgb = z.ncomp == 3 && (z.rgb == 3 || (z.app14 == 0 && !z.jfif));
+    struct Res { int hs, vs, ystep, w_lores, ypos; const uint8_t *line0, *line1; std::vector<uint8_t> buf; };
+    Res res[3];
+    for (int k = 0; k < z.ncomp; k++) {
+        Res& r = res[k];
+        r.hs = z.h_max / z.comp[k].h; r.vs = z.v_max / z.comp[k].v;
+        r.ystep = r.vs >> 1; r.w_lores = (z.img_x + r.hs - 1) / r.hs; r.ypos = 0;
+        r.line0 = r.line1 = z.comp[k].data.data();
+        r.buf.assign((size_t)z.img_x + 3 + 8, 0);
+    }
+    auto div4 = [](int x) { return (uint8_t)(x >> 2); };
+    auto div16 = [](int x) { return (uint8_t)(x >> 4); };
+    for (int j = 0; j < z.img_y; j++) {
+        const uint8_t* row[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < z.ncomp; k++) {
+            Res& r = res[k];
+            const bool y_bot = r.ystep >= (r.vs >> 1);
+            const uint8_t* near = y_bot ? r.line1 : r.line0;
+            const uint8_t* far = y_bot ? r.line0 : r.line1;
+            uint8_t* out = r.buf.data();
+            const int w = r.w_lores;
+            if (r.hs == 1 && r.vs == 1) row[k] = near;
+            else {
+                if (r.hs == 1 && r.vs == 2) { for (int i = 0; i < w; i++) out[i] = div4(3 * near[i] + far[i] + 2); }
+                else if (r.hs == 2 && r.vs == 1) {
+                    if (w == 1) out[0] = out[1] = near[0];
+                    else {
+                        out[0] = near[0]; out[1] = div4(near[0] * 3 + near[1] + 2);
+                        int i = 1;
+                        for (; i < w - 1; i++) { const int t = 3 * near[i] + 2; out[i * 2] = div4(t + near[i - 1]); out[i * 2 + 1] = div4(t + near[i + 1]); }
+                        out[i * 2] = div4(near[w - 2] * 3 + near[w - 1] + 2); out[i * 2 + 1] = near[w - 1];
+                    }
+                } else if (r.hs == 2 && r.vs == 2) {
+                    if (w == 1) out[0] = out[1] = div4(3 * near[0] + far[0] + 2);
+                    else {
+                        int t1 = 3 * near[0] + far[0];
+                        out[0] = div4(t1 + 2);
+                        for (int i = 1; i < w; i++) { const int t0 = t1; t1 = 3 * near[i] + far[i]; out[i * 2 - 1] = div16(3 * t0 + t1 + 8); out[i * 2] = div16(3 * t1 + t0 + 8); }
+                        out[w * 2 - 1] = div4(t1 + 2);
+                    }
+                } else { for (int i = 0; i < w; i++) for (int q = 0; q < r.hs; q++) out[i * r.hs + q] = near[i]; }
+                row[k] = out;
+            }
+            if (++r.ystep >= r.vs) {
+                r.ystep = 0; r.line0 = r.line1;
+                if (++r.ypos < z.comp[k].y) r.line1 += z.comp[k].w2;
+            }
+        }
+        uint8_t* o = im.px.data() + (size_t)j * im.w * 4;
+        if (z.ncomp == 1) { for (int i = 0; i < im.w; i++, o += 4) { o[0] = o[1] = o[2] = row[0][i]; o[3] = 255; } }
+        else if (is_rgb) { for (int i = 0; i < im.w; i++, o += 4) { o[0] = row[0][i]; o[1] = row[1][i]; o[2] = row[2][i]; o[3] = 255; } }
+        else {
+            auto fx = [](float x) { return ((int)(x * 4096.0f + 0.5f)) << 8; };
+            static const int cr_r = fx(1.40200f), cr_g = -fx(0.71414f), cb_g = -fx(0.34414f), cb_b = fx(1.77200f);
+            for (int i = 0; i < im.w; i++, o += 4) {
+                const int y_fixed = (row[0][i] << 20) + (1 << 19);
+                const int cr = row[2][i] - 128, cb = row[1][i] - 128;
+                int rr = y_fixed + cr * cr_r;
+                int gg = y_fixed + cr * cr_g + (int)((unsigned)(cb * cb_g) & 0xffff0000u);
+                int bb = y_fixed + cb * cb_b;
+                rr >>= 20; gg >>= 20; bb >>= 20;
+                o[0] = JpegDec::clamp8(rr); o[1] = JpegDec::clamp8(gg); o[2] = JpegDec::clamp8(bb); o[3] = 255;
+            }
+        }
+    }
+    return im;
+}
+
+// what the image bytes are decides the decoder, as in stb_image (the glTF mimeType is not consulted there either)
+Image decode_image(const uint8_t* d, size_t n) {
+    if (n >= 2 && d[0] == 0xff && d[1] == 0xd8) return decode_jpeg(d, n);
+    return decode_png(d, n);
 }
 
 // ---------------------------------------------------------------- textures as the reference stores them (Texture.h, USE_CHAR 1)
@@ -499,7 +908,7 @@ struct Loader {
         const size_t off = to_size(bv.number("byteOffset", 0), bin.size(), "image byteOffset");
         const size_t len = to_size(bv.number("byteLength", 0), bin.size(), "image byteLength");
         if (len > bin.size() - off) fail("glTF: image reaches beyond the binary chunk");
-        const Image img = decode_png(bin.data() + off, len);
+        const Image img = decode_image(bin.data() + off, len);
         base.push_back(load_texture(img, conv, with_scale, scale_v));
         return tex_cache[key] = (int)base.size() - 1;
     }
@@ -814,6 +1223,25 @@ extern "C" int srx_gltf_load(const char* path, srx_gltf** out) {
 }
 
 extern "C" void srx_gltf_destroy(srx_gltf* g) { delete g; }
+
+extern "C" int srx_image_decode(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint8_t* rgba, size_t capacity) {
+    if (!data || !width || !height) { srx_set_error("srx_image_decode: null argument"); return 1; }
+    try {
+        const Image im = decode_image(data, n);
+        *width = (uint32_t)im.w; *height = (uint32_t)im.h;
+        if (rgba) {
+            if (capacity < im.px.size()) { srx_set_error("srx_image_decode: output buffer smaller than width * height * 4"); return 1; }
+            std::memcpy(rgba, im.px.data(), im.px.size());
+        }
+        return 0;
+    } catch (const Fail& e) {
+        srx_set_error(std::string("srx_image_decode: ") + e.msg);
+        return 1;
+    } catch (const std::exception& e) {
+        srx_set_error(std::string("srx_image_decode: ") + e.what());
+        return 1;
+    }
+}
 
 extern "C" int srx_gltf_get(const srx_gltf* g, const srx_tri** tris, uint32_t* n_tris, const srx_material** materials, uint32_t* n_materials,
                             const srx_texture** textures, uint32_t* n_textures, const srx_sun** suns, uint32_t* n_suns, srx_camera* camera) {

@@ -48,3 +48,16 @@ def load_gltf_file(path, res_x, res_y, subdiv=1, max_generations=10, monte_carlo
     desc.monte_carlo_max = monte_carlo_max
     desc.monte_carlo_modifier = monte_carlo_modifier
     return desc
+
+
+def decode_image(data):
+    """Embedded image bytes (8-bit PNG or baseline JPEG) -> (h, w, 4) uint8, as `stbi_load_from_memory(..., 4)` gives
+    them to tinygltf's LoadImageData (`srx_image_decode`)."""
+    L = _lib.lib()
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_uint32(), C.c_uint32()
+    check(L.srx_image_decode(buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(buf)), C.byref(w), C.byref(h), None, C.c_size_t(0)), "srx_image_decode")
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    check(L.srx_image_decode(buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(buf)), C.byref(w), C.byref(h),
+                             out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)), "srx_image_decode")
+    return out

@@ -274,3 +274,94 @@ def test_crafted_numbers_cannot_pass_the_range_checks(tmp_path):
     scene(with_bomb, True).write(tmp_path / "bomb.glb")
     with pytest.raises(_lib.SrxError, match="more data than the image needs"):
         gltf.load_gltf_file(tmp_path / "bomb.glb", 4, 4)
+
+
+STB = os.path.join(os.path.dirname(REF), "libref_stb.so")
+JPEG_CASES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_cases.npz")
+
+
+def _stb_decode(data):
+    import ctypes as C
+    R = C.CDLL(STB)
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h, n = C.c_int(), C.c_int(), C.c_int()
+    if R.ref_stb_decode(buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(w), C.byref(h), C.byref(n), None):
+        return None
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    R.ref_stb_decode(buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(w), C.byref(h), C.byref(n), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def test_jpeg_decode_matches_committed_stb_image_bytes(tmp_path):
+    """Baseline JPEG textures (what Blender's glTF exporter writes by default): the product's decoder against the bytes
+    the reference's own vendored stb_image gives (tests/golden/jpeg_cases.npz, made by tests/golden/make_jpeg_golden.py
+    with Pillow as the encoder): every sampling layout stb has a filter for, grayscale, odd sizes down to 1x1, restart
+    intervals, Adobe RGB; bit-exact. The PNG decoder is checked against the same source."""
+    Z = np.load(JPEG_CASES)
+    names = [k[5:] for k in Z.files if k.startswith("file_")]
+    assert len(names) >= 28
+    for name in names:
+        data = Z["file_" + name].tobytes()
+        if name.startswith("progressive"):
+            with pytest.raises(_lib.SrxError, match="progressive"):
+                gltf.decode_image(data)
+            continue
+        got = gltf.decode_image(data)
+        want = Z["rgba_" + name]
+        assert got.shape == want.shape, name
+        assert np.array_equal(got, want), (name, int((got != want).sum()))
+    # through the loader: a JPEG base-colour texture ends as the reference's 3-byte texels (Texture.h:120-131)
+    data = Z["file_420_33x17"].tobytes()
+    g = GlbWriter()
+    g.accessor(np.zeros((1, 3), np.float32), "VEC3")
+    g.js["images"].append({"bufferView": g.view(data), "mimeType": "image/jpeg"})
+    g.js["textures"].append({"source": 0})
+    g.js["materials"].append({"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}})
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.5]], np.float32)
+    g.js["meshes"].append({"primitives": [{"attributes": {"POSITION": g.accessor(tri, "VEC3")}, "indices": g.accessor(np.array([0, 1, 2], np.uint16), "SCALAR"), "material": 0}]})
+    g.js["nodes"] = [{"mesh": 0}, {"camera": 0}]
+    g.js["cameras"].append({"type": "perspective", "perspective": {"aspectRatio": 1.0, "yfov": 0.7}})
+    g.write(tmp_path / "j.glb")
+    desc = gltf.load_gltf_file(tmp_path / "j.glb", 4, 4)
+    sro_gltf.jpeg_decoder = lambda b: Z["rgba_420_33x17"]
+    try:
+        _compare(desc, sro_gltf.load(tmp_path / "j.glb"))
+    finally:
+        sro_gltf.jpeg_decoder = None
+    assert len(desc.textures) == 1 and desc.textures[0].rgb8.shape == (17, 33, 3)
+    # damaged files fail with an error, not a crash: every truncation of one file, and bytes flipped in its headers
+    rng = np.random.default_rng(2)
+    for cut in list(range(0, 700, 7)) + [len(data) - 2]:
+        try:
+            gltf.decode_image(data[:cut])
+        except _lib.SrxError:
+            pass
+    for _ in range(300):
+        b = bytearray(data)
+        for k in rng.integers(2, 640, 3):
+            b[k] = rng.integers(0, 256)
+        try:
+            gltf.decode_image(bytes(b))
+        except _lib.SrxError:
+            pass
+
+
+@pytest.mark.skipif(not os.path.exists(STB), reason="oracle/_ref not built (needs /root/reference; run __graft_entry__.build())")
+def test_image_decoders_match_stb_image_built_from_the_reference():
+    """The committed expected bytes are what the reference's stb_image gives now, and fresh files (other seeds and
+    qualities than the committed ones, written here with Pillow when it is importable) decode identically."""
+    Z = np.load(JPEG_CASES)
+    for k in Z.files:
+        if k.startswith("file_") and not k.startswith("file_progressive"):
+            assert np.array_equal(_stb_decode(Z[k].tobytes()), Z["rgba_" + k[5:]]), k
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(11)
+    for i in range(40):
+        w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        img = np.clip(rng.normal(128, 60, (h, w, 3)) + np.linspace(-80, 80, w)[None, :, None], 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        PIL.fromarray(img if i % 5 else img[..., 0]).save(b, "JPEG", quality=int(rng.integers(5, 100)), subsampling=int(rng.integers(0, 3)),
+                                                          restart_marker_blocks=int(rng.integers(0, 4)), optimize=bool(i % 2))
+        got, want = gltf.decode_image(b.getvalue()), _stb_decode(b.getvalue())
+        assert np.array_equal(got, want), (i, w, h)
