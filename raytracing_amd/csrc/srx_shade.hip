@@ -168,7 +168,12 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #ifndef SRX_SHADE_WAVES
 #define SRX_SHADE_WAVES 4
 #endif
-__global__ __launch_bounds__(64 * SRX_SHADE_WAVES) void k_shade(GScene sc, ShadeArgs a) {
+#ifdef SRX_SHADE_MIN_WAVES   // experiments: cap the registers for this many waves per SIMD
+#define SRX_SHADE_BOUNDS __launch_bounds__(64 * SRX_SHADE_WAVES, SRX_SHADE_MIN_WAVES)
+#else
+#define SRX_SHADE_BOUNDS __launch_bounds__(64 * SRX_SHADE_WAVES)
+#endif
+__global__ SRX_SHADE_BOUNDS void k_shade(GScene sc, ShadeArgs a) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
