@@ -512,340 +512,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     }
 }
 
-// ---------------------------------------------------------------- two rays per octet in flight
-// The same traversal, ray for ray, with TWO rays per octet alive at a time (slots 0 and 1, each with its own stack
-// column, best-hit record and overflow bookkeeping). The loop alternates between the slots: a phase first finishes the
-// trip whose lines were requested at the end of the slot's previous phase (node or packet test, push), then ends / renews
-// the ray, pops the next entry and requests its lines, and hands over to the other slot, whose lines have had this whole
-// phase to arrive. One wave therefore has two independent gathers in flight where k_trace has one; the price is
-// registers (the waiting slot's lines and ray constants stay live), i.e. fewer waves per SIMD.
-// Results are identical to k_trace's: every ray walks exactly the same sequence of entries.
-template <int MODE, int K, bool SPILL>
-__global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace2(GScene sc, TraceArgs a) {
-    static_assert(K >= 2, "two slots need at least two rays per octet");
-    constexpr uint32_t SRX_RAYS_PER_BLOCK = SRX_OCTETS_PER_BLOCK * K;
-    extern __shared__ unsigned long long s_mem[];
-    const int D = a.lds_depth;
-    // LDS: [slot][depth][octet] stack entries, [slot][octet] best-hit records, the ray pool, [slot][octet] parked counts
-    unsigned long long* const s_stack_all = s_mem;
-    uint4* const s_best_all = (uint4*)(s_mem + (size_t)2 * D * SRX_OCTETS_PER_BLOCK);
-    float4* const s_setup = (float4*)(s_best_all + 2 * SRX_OCTETS_PER_BLOCK);
-    float2* const s_pt = (float2*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);
-    uint32_t* const s_spilled_all = (uint32_t*)(s_pt + K * SRX_OCTETS_PER_BLOCK);
-    const int sub = threadIdx.x & 7;
-    const int oct = threadIdx.x >> 3;
-    const int lane = threadIdx.x & 63;
-    const int oct_shift = lane & ~7;
-    const uint32_t sub16 = (uint32_t)sub << 4;
-    const uint32_t zero_key_limit = sub == 0 ? 7u : 0u;
-    const uint32_t n_rays = a.n_ptr ? min(*a.n_ptr, a.n) : a.n;
-    const uint32_t nblk = a.n_ptr ? min(gridDim.x, ((n_rays + SRX_RAYS_PER_BLOCK - 1u) / SRX_RAYS_PER_BLOCK + 7u) & ~7u) : gridDim.x;
-    if (blockIdx.x >= nblk) return;
-    const uint32_t per_xcd = (nblk + 7u) >> 3;
-    const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    const uint32_t ray0 = lblock * SRX_RAYS_PER_BLOCK + oct;
-
-    // ---- set-up of all K rays of the octet at once (as in k_trace)
-    bool fast;
-    {
-        const uint32_t myray = ray0 + (uint32_t)sub * SRX_OCTETS_PER_BLOCK;
-        const bool mine = sub < K && lblock < nblk && myray < n_rays;
-        f3 so, sd;
-        if (mine) {
-            const float* po = a.org + (size_t)myray * a.org_stride;
-            so = f3(po[0], po[1], po[2]);
-            if (MODE == 2) {
-                const GSun& s = sc.suns[a.shadow_q[myray].pixel_sun >> 24];
-                sd = f3(s.dir[0], s.dir[1], s.dir[2]);
-            } else {
-                const float* pd = a.dir + (size_t)myray * a.dir_stride;
-                sd = f3(pd[0], pd[1], pd[2]);
-            }
-        }
-        const f3 sfused = (so * -1.0f) / sd;
-        const f3 sinv = f3(1.0f) / sd;
-        const bool finite6 = well_defined(sfused.x) && well_defined(sfused.y) && well_defined(sfused.z) &&
-                             well_defined(sinv.x) && well_defined(sinv.y) && well_defined(sinv.z);
-        fast = !__any(mine && !finite6);
-        const float sdd = __fmaf_rn(sd.z, sd.z, __fmaf_rn(sd.y, sd.y, sd.x * sd.x));
-        const float sdmin = fminf(fminf(fabsf(sd.x), fabsf(sd.y)), fabsf(sd.z));
-        const float spad = __fmaf_rn(SRX_FILTER_PAD_ABS, fmaxf(fmaxf(fabsf(so.x), fabsf(so.y)), fabsf(so.z)), sc.filter_pad);
-        const float spt = (finite6 && sdd >= 1e-12f && sdd <= 1e12f && sdmin * sdmin >= 1e-30f * sdd)
-                              ? spad * fmaxf(fmaxf(fabsf(sinv.x), fabsf(sinv.y)), fabsf(sinv.z)) : __builtin_inff();
-        const float sq = 127.0f / sqrtf(sdd);
-        const uint32_t sdq = ((uint32_t)(int)rintf(sd.x * sq) & 255u) | (((uint32_t)(int)rintf(sd.y * sq) & 255u) << 8) | (((uint32_t)(int)rintf(sd.z * sq) & 255u) << 16);
-        if (sub < K) {
-            float4* dst = s_setup + ((size_t)sub * SRX_OCTETS_PER_BLOCK + oct) * 3;
-            dst[0] = make_float4(sd.x, sd.y, sd.z, so.x);
-            dst[1] = make_float4(so.y, so.z, sinv.x, sinv.y);
-            dst[2] = make_float4(sinv.z, sfused.x, sfused.y, sfused.z);
-            s_pt[sub * SRX_OCTETS_PER_BLOCK + oct] = make_float2(spt, u2f(sdq));
-        }
-    }
-    int block_rays = 0;
-    if (lblock < nblk && lblock * SRX_RAYS_PER_BLOCK < n_rays) block_rays = (int)min(SRX_RAYS_PER_BLOCK, n_rays - lblock * SRX_RAYS_PER_BLOCK);
-    int next_j = 2 * SRX_OCTETS_PER_BLOCK;     // wave-uniform: the first ray of the block no slot has taken yet
-    uint32_t n_nodes = 0, n_packets = 0;
-
-    struct Slot {
-        float4 A, B, r0; float2 C;             // requested at the end of the slot's last phase
-        uint32_t link; bool go;                // the entry they belong to
-        // (1/d, -o/d and the filter constants are read from the ray's pool record, s_setup[3 cur] and s_pt[cur], by the
-        // node trips: LDS reads that cost less than nine more live registers per slot)
-        float best_t; int sp, cur; uint32_t ray;
-        int spill_slot; unsigned long long spilled_mask;   // wave-uniform
-    };
-
-    auto init_slot = [&](Slot& S, int which) {
-        const int j = which * SRX_OCTETS_PER_BLOCK + oct;
-        S.cur = j < block_rays ? j : -1;
-        S.ray = lblock * SRX_RAYS_PER_BLOCK + (uint32_t)j;
-        S.best_t = SRX_MISS_DISTANCE;
-        S.sp = S.cur >= 0 ? 0 : -1;
-        S.go = false; S.link = 0;
-        S.A = S.B = S.r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); S.C = make_float2(0.0f, 0.0f);
-        S.spill_slot = -1; S.spilled_mask = 0ull;
-        if (sub == 0) s_stack_all[(size_t)which * D * SRX_OCTETS_PER_BLOCK + oct] = 0ull;
-        if (SPILL && sub == 0) s_spilled_all[which * SRX_OCTETS_PER_BLOCK + oct] = 0u;
-    };
-    __builtin_amdgcn_wave_barrier();
-    Slot S0, S1;
-    init_slot(S0, 0);
-    init_slot(S1, 1);
-    __builtin_amdgcn_wave_barrier();
-
-    auto phase = [&](Slot& S, const int which) {
-        unsigned long long* const s_stack = s_stack_all + (size_t)which * D * SRX_OCTETS_PER_BLOCK;
-        uint4* const s_best = s_best_all + which * SRX_OCTETS_PER_BLOCK;
-        uint32_t* const s_spilled = s_spilled_all + which * SRX_OCTETS_PER_BLOCK;
-        // ---- 1. the trip whose lines were requested a phase ago
-        if (S.go) {
-            const uint32_t link = S.link;
-            const bool leaf = (link & SRX_LINK_LEAF) != 0u;
-            const uint32_t off = (link << 7) | sub16;
-            const float4 A = S.A, B = S.B, r0 = S.r0;
-            const f3 d(r0.x, r0.y, r0.z);
-            if (!leaf) {
-                n_nodes++;
-                const float4* const ray_setup = s_setup + S.cur * 3;
-                const float2 r1 = *(const float2*)((const char*)ray_setup + 24);
-                const float4 r2 = ray_setup[2];
-                const float2 pq = s_pt[S.cur];
-                const f3 inv(r1.x, r1.y, r2.x), fused(r2.y, r2.z, r2.w);
-                const float c1 = SRX_FILTER_PAD_REL * fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
-                bool may_hit;
-                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused, d, (int)f2u(pq.y), c1, pq.x, may_hit)
-                                         : node_test<false>(A, B, inv, fused, d, (int)f2u(pq.y), c1, pq.x, may_hit);
-                const uint32_t kb = (rb & ~7u) | (uint32_t)sub;
-                const bool valid = (rb & 0x7fffffffu) > zero_key_limit && may_hit;
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid);
-                const uint32_t vmask = (uint32_t)(bal >> oct_shift) & 0xFFu;
-                const int nvalid = __popc(vmask);
-                int rank;
-                if (MODE == 0) {
-                    const uint32_t ord = valid ? (kb ^ ((uint32_t)((int32_t)kb >> 31) | 0x80000000u)) : 0xFFFFFFFFu;
-                    rank = octet_rank_u32(ord);
-                } else {
-                    rank = __popc(vmask & ((1u << sub) - 1u));
-                }
-                if (valid) s_stack[(S.sp + nvalid - rank) * SRX_OCTETS_PER_BLOCK + oct] = ((unsigned long long)rb << 32) | f2u(B.z);
-                S.sp += nvalid;
-            } else {
-                const float2 C = S.C;
-                const float2 r1 = *(const float2*)(s_setup + S.cur * 3 + 1);
-                const f3 o(r0.w, r1.x, r1.y);
-                if ((link & (SRX_LINK_MORE_MAX << SRX_LINK_MORE_SHIFT)) != 0u) {
-                    S.sp++;
-                    if (sub == 0) s_stack[S.sp * SRX_OCTETS_PER_BLOCK + oct] = (0xFF800000ull << 32) | (link + 3u - (1u << SRX_LINK_MORE_SHIFT));
-                }
-                n_packets++;
-                const float e1x = A.w, e1y = B.x, e1z = B.y;
-                const float e2x = B.z, e2y = C.x, e2z = C.y;
-                const float c1 = d.z * e2y, c2 = d.x * e2z, c3 = d.y * e2x;
-                const float px = __fmaf_rn(d.y, e2z, -c1), py = __fmaf_rn(d.z, e2x, -c2), pz = __fmaf_rn(d.x, e2y, -c3);
-                const float det = __fmaf_rn(e1z, pz, __fmaf_rn(e1y, py, e1x * px));
-                const float invDet = 1.0f / det;
-                const float tx = o.x - A.x, ty = o.y - A.y, tz = o.z - A.z;
-                const float q1 = tz * e1y, q2 = tx * e1z, q3 = ty * e1x;
-                const float qx = __fmaf_rn(ty, e1z, -q1), qy = __fmaf_rn(tz, e1x, -q2), qz = __fmaf_rn(tx, e1y, -q3);
-                const float uu = invDet * __fmaf_rn(tz, pz, __fmaf_rn(ty, py, tx * px));
-                const float vv = invDet * __fmaf_rn(d.z, qz, __fmaf_rn(d.y, qy, d.x * qx));
-                const float tt = invDet * __fmaf_rn(e2z, qz, __fmaf_rn(e2y, qy, e2x * qx));
-                const bool pass = (uu >= 0.0f) && (vv >= 0.0f) && ((uu + vv) <= 1.0f);
-                const bool cand = pass && (tt > 0.0f) && (tt < S.best_t);
-                if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
-                    const uint32_t tb = cand ? f2u(tt) : 0xFFFFFFFFu;
-                    const uint32_t m = octet_min_u32(tb);
-                    if (m != 0xFFFFFFFFu) {
-                        S.best_t = u2f(m);
-                        if (MODE == 0) {
-                            const unsigned long long wb = __builtin_amdgcn_ballot_w64(tb == m);
-                            const int w = __ffs((int)((uint32_t)(wb >> oct_shift) & 0xFFu)) - 1;
-                            if (sub == w) s_best[oct] = make_uint4(f2u(uu), f2u(vv), off + 256u + 64u - 12u * (uint32_t)sub, 0u);
-                        } else if (S.best_t <= 9999.0f) {
-                            S.sp = -1;
-                            if (SPILL && S.spilled_mask != 0ull) s_spilled[oct] = 0u;
-                        }
-                    }
-                }
-            }
-        }
-        // ---- 2. room for the next push (SPILL), as in k_trace, per slot
-        if (SPILL) {
-            const bool over = S.sp > D - 8;
-            const unsigned long long ob = __builtin_amdgcn_ballot_w64(over);
-            if ((ob | S.spilled_mask) != 0ull) {
-                const int H = D >> 1;
-                uint32_t parked = s_spilled[oct];
-                const bool under = S.sp < 0 && parked > 0u;
-                if (ob != 0ull && S.spill_slot < 0) {
-                    int got = -1;
-                    if (lane == 0) {
-                        for (int tries = 0; tries < (1 << 16) && got < 0; tries++) {
-                            const uint32_t i = atomicAdd(&sc.spill_ctl[0], 1u) & (SRX_SPILL_SLOTS - 1u);
-                            if (atomicCAS(&sc.spill_ctl[16 + i], 0u, 1u) == 0u) got = (int)i;
-                        }
-                        if (got < 0) atomicExch(&sc.spill_ctl[1], 1u);
-                        else atomicAdd(&sc.spill_ctl[2], 1u);
-                    }
-                    S.spill_slot = __builtin_amdgcn_readfirstlane(got);
-                }
-                unsigned long long* const area = sc.spill_area + ((size_t)(S.spill_slot < 0 ? 0 : S.spill_slot) * SRX_OCTETS_PER_BLOCK + oct) * (size_t)sc.stack_depth;
-                if (over) {
-                    if (S.spill_slot < 0) {
-                        S.sp = -1; parked = 0u;
-                    } else {
-                        for (int i = sub; i < H; i += 8)
-                            __hip_atomic_store(&area[parked + i], s_stack[i * SRX_OCTETS_PER_BLOCK + oct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        for (int i = sub; i + H <= S.sp; i += 8) {
-                            const unsigned long long e = s_stack[(i + H) * SRX_OCTETS_PER_BLOCK + oct];
-                            s_stack[i * SRX_OCTETS_PER_BLOCK + oct] = e;
-                        }
-                        S.sp -= H; parked += (uint32_t)H;
-                    }
-                } else if (under) {
-                    for (int i = sub; i < H; i += 8)
-                        s_stack[i * SRX_OCTETS_PER_BLOCK + oct] = __hip_atomic_load(&area[parked - H + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    S.sp = H - 1; parked -= (uint32_t)H;
-                }
-                if (sub == 0) s_spilled[oct] = parked;
-                S.spilled_mask = __builtin_amdgcn_ballot_w64(parked > 0u);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        // ---- 3. a ray that has ended hands in its result; its slot takes the next ray of the block nobody has taken
-        {
-            const bool ended = S.sp < 0 && S.cur >= 0;
-            const unsigned long long eb = __builtin_amdgcn_ballot_w64(ended && sub == 0);
-            if (eb != 0ull) {
-                if (ended) {
-                    const uint32_t r = S.ray;
-                    if (sub == 0) {
-                        if (MODE == 0) {
-                            GHit h;
-                            const bool hit = S.best_t < SRX_MISS_DISTANCE;
-                            const uint4 b = s_best[oct];
-                            h.material = 0xFFFFFFFFu; h.tri_index = 0;
-                            if (hit) {
-                                h.material = *(const uint32_t*)(sc.geom + (size_t)b.z);
-                                h.tri_index = *(const int32_t*)(sc.geom + (size_t)b.z + 32);
-                            }
-                            h.t = hit ? S.best_t : -1.0f;
-                            h.u = hit ? u2f(b.x) : -1.0f; h.v = hit ? u2f(b.y) : -1.0f;
-                            a.hits[r] = h;
-                            if (a.advanced_org3) {
-                                const float4 q0 = s_setup[S.cur * 3];
-                                const float2 q1 = *(const float2*)(s_setup + S.cur * 3 + 1);
-                                const f3 o(q0.w, q1.x, q1.y), d(q0.x, q0.y, q0.z);
-                                const f3 p = o + (S.best_t * d) * 0.999f;
-                                a.advanced_org3[3 * (size_t)r] = p.x; a.advanced_org3[3 * (size_t)r + 1] = p.y; a.advanced_org3[3 * (size_t)r + 2] = p.z;
-                            }
-                        } else if (MODE == 1) {
-                            a.lit[r] = S.best_t > 9999.0f ? 1 : 0;
-                        }
-                    }
-                    if (MODE == 2 && sub < 3 && S.best_t > 9999.0f) {
-                        const GShadow& s = a.shadow_q[r];
-                        const float c = sub == 0 ? s.cr : (sub == 1 ? s.cg : s.cb);
-                        if (c != 0.0f) atomicAdd(&a.sample3[3 * (size_t)(s.pixel_sun & 0x00FFFFFFu) + sub], c);
-                    }
-                    const int j = next_j + __popcll(eb & ((1ull << oct_shift) - 1ull));
-                    S.cur = -1;
-                    if (j < block_rays) {
-                        S.cur = j;
-                        S.ray = lblock * SRX_RAYS_PER_BLOCK + (uint32_t)j;
-                        S.best_t = SRX_MISS_DISTANCE;
-                        S.sp = 0;
-                        if (sub == 0) s_stack[oct] = 0ull;
-                    }
-                }
-                next_j += __popcll(eb);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- 4. pop until an entry survives the distance cull (Core.h:63-68) and request its lines
-        __builtin_amdgcn_s_setprio(3);
-        S.go = false;
-        while (S.sp >= 0) {
-            const unsigned long long e = s_stack[S.sp * SRX_OCTETS_PER_BLOCK + oct];
-            S.sp--;
-            if (!(u2f((uint32_t)(e >> 32)) >= S.best_t)) { S.link = (uint32_t)e; S.go = true; break; }
-        }
-        {
-            // Always three loads, by every lane, in straight-line code: the compiler's wait-count pass can then tell the
-            // other slot's phase to wait for ITS lines only (vmcnt(3)) and leave these in flight; under a branch it falls
-            // back to vmcnt(0) and the two slots run one after the other. A lane with nothing to fetch reads the root
-            // record, a node trip reads its first line twice.
-            const uint32_t off = S.go ? ((S.link << 7) | sub16) : sub16;
-            const char* const rec = sc.geom + (size_t)off;
-            const bool leaf = S.go && (S.link & SRX_LINK_LEAF) != 0u;
-            S.A = *(const float4*)rec;
-            S.B = *(const float4*)(rec + 128);
-            S.C = *(const float2*)(rec + (leaf ? 256 - 8 * sub : 0));
-            S.r0 = s_setup[max(S.cur, 0) * 3];
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    while (__builtin_amdgcn_ballot_w64(S0.cur >= 0 || S1.cur >= 0) != 0ull) {
-        phase(S0, 0);
-        phase(S1, 1);
-    }
-
-    if (SPILL && lane == 0) {
-        if (S0.spill_slot >= 0) __hip_atomic_store(&sc.spill_ctl[16 + S0.spill_slot], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (S1.spill_slot >= 0) __hip_atomic_store(&sc.spill_ctl[16 + S1.spill_slot], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (a.counters) {
-        uint32_t wn = sub == 0 ? n_nodes : 0u, wp = sub == 0 ? n_packets : 0u;
-#pragma unroll
-        for (int off = 32; off >= 8; off >>= 1) {
-            wn += (uint32_t)__shfl_xor((int)wn, off, 64);
-            wp += (uint32_t)__shfl_xor((int)wp, off, 64);
-        }
-        if (lane == 0) {
-            unsigned long long* c = a.counters + (size_t)(blockIdx.x & a.counter_slot_mask) * a.counter_slot_stride;
-            atomicAdd(&c[0], (unsigned long long)wn);
-            atomicAdd(&c[1], (unsigned long long)wp);
-        }
-    }
-}
-
-static size_t trace2_lds_bytes(int lds_depth, int k, bool spill) {
-    return (size_t)2 * lds_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + 2 * SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
-           (size_t)SRX_OCTETS_PER_BLOCK * k * (3 * sizeof(float4) + sizeof(float2)) + (spill ? 2 * SRX_OCTETS_PER_BLOCK * sizeof(uint32_t) : 0);
-}
-
 static size_t trace_lds_bytes(int lds_depth, int k, bool spill) {
     return (size_t)lds_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
            (size_t)SRX_OCTETS_PER_BLOCK * k * (3 * sizeof(float4) + sizeof(float2)) + (spill ? SRX_OCTETS_PER_BLOCK * sizeof(uint32_t) : 0);
-}
-
-template <int K, bool SPILL>
-static void launch_k2(int mode, uint32_t blocks, size_t lds, const GScene& sc, const TraceArgs& a, hipStream_t stream) {
-    if (mode == 0) hipLaunchKernelGGL((k_trace2<0, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_trace2<1, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
-    else hipLaunchKernelGGL((k_trace2<2, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
 }
 
 template <int K, bool SPILL>
@@ -892,13 +561,6 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
     const uint32_t rays_per_block = SRX_OCTETS_PER_BLOCK * (uint32_t)k;
     uint32_t blocks = (a.n + rays_per_block - 1) / rays_per_block;
     blocks = (blocks + 7u) & ~7u;   // multiple of 8 so the XCD map covers every logical block exactly once
-    static const int slots = [] { const char* e = getenv("SRX_TRACE_SLOTS"); return e ? atoi(e) : 1; }();
-    if (slots == 2 && k >= 4) {
-        const size_t lds2 = trace2_lds_bytes(depth, k, spill);
-        if (spill) { if (k == 8) launch_k2<8, true>(mode, blocks, lds2, sc, a, stream); else launch_k2<4, true>(mode, blocks, lds2, sc, a, stream); }
-        else { if (k == 8) launch_k2<8, false>(mode, blocks, lds2, sc, a, stream); else launch_k2<4, false>(mode, blocks, lds2, sc, a, stream); }
-        return hipGetLastError();
-    }
     const size_t lds = trace_lds_bytes(depth, k, spill);
     if (spill) {
         if (k == 8) launch_k<8, true>(mode, blocks, lds, sc, a, stream);
