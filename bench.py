@@ -51,6 +51,7 @@ def parse():
                          "MIN_SAMPLES, analysis every 4 visits) and report it under config.adaptive")
     ap.add_argument("--fast-build", action="store_true", help="not the headline run: package the scene with srx_package_create_fast (a different tree, "
                     "tight leaves; hits equal the reference tree's through the order tables) and report the same metric over it")
+    ap.add_argument("--no-fast-tree", action="store_true", help="skip the extra leg that repeats the measurement over the fast builder's tree (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: exchange staged through the host)")
     ap.add_argument("--passes-per-call", type=int, default=0, metavar="B",
                     help="sample passes (steps) that share their kernel launches; 0 = the number of ranks, so a rank's launches stay as "
@@ -146,6 +147,34 @@ def cpu_baseline(desc, cam, seed, threads_all):
     }
 
 
+def fast_tree_leg(args, RE, desc, cam, rect, share, accum, aux, B, barrier):
+    """Not the headline: the same passes over the tree of the opt-in fast builder (srx_package_create_fast: binned SAH,
+    tight leaves; hits equal the reference tree's through the order tables except on exact ties and for rays with a zero
+    direction component, tests/test_fast_builder_gpu.py). `value` stays the bit-compatible tree's."""
+    from raytracing_amd import engine
+    t0 = time.perf_counter()
+    PSf = engine.package(desc, fast=True)
+    t_pack = time.perf_counter() - t0
+    RE.load_scene(PSf)
+    RE.set_timing(True, ray_capacity=args.ray_capacity)
+    steps = max(1, min(args.steps, 3))
+    RE.trace_pass(cam, rect, 0, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share, n_passes=1)      # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    tot = {}
+    for p in range(1, 1 + steps, B):
+        c = RE.trace_pass(cam, rect, p, args.seed, accum, aux, ray_capacity=args.ray_capacity, interleave=share, n_passes=min(B, 1 + steps - p))
+        for k, v in c.items():
+            tot[k] = tot.get(k, 0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    rays = float(tot["rays_processed"])
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "steps": steps, "ms_per_step": dt / steps * 1e3, "scene_package_s": t_pack,
+            "builder": "srx_package_create_fast (opt-in; a different tree behind the order tables)",
+            "node_tests_per_ray": tot["nodes"] / max(1.0, rays), "packet_tests_per_ray": tot["packets"] / max(1.0, rays),
+            "stack_depth": RE.stack_bound()}
+
+
 def adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, barrier):
     """SceneManager's mode-1 loop (SceneManager.h:970-993) on the GPU: visits of every 4x4 block with the
     controller's priorities, analyze_noise + balance_threads every 4 visits (the reference: every 2 s)."""
@@ -225,7 +254,6 @@ def main():
     share = (tiles.TILE, rank, world) if args.share_of <= 1 else (tiles.TILE, 0, args.share_of)
     accum = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
     aux = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
-    my_rows = tiles.interleaved_rows(rank, world, H).cuda()
 
     def barrier():
         if world > 1:
@@ -392,6 +420,8 @@ def main():
         }
         if adaptive is not None:
             out["config"]["adaptive"] = adaptive
+        if world == 1 and not args.fast_build and not args.no_fast_tree and args.share_of <= 1:
+            out["fast_tree"] = fast_tree_leg(args, RE, desc, cam, rect, share, accum, aux, B, barrier)
         if not args.no_cpu_baseline and world == 1:
             threads = args.cpu_threads or host_cpu()[2]
             out["cpu_baseline"] = cpu_baseline(desc, cam, args.seed, threads)

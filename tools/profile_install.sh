@@ -9,3 +9,5 @@ cp $(find $T/stats1 -name "*kernel_stats.csv" | head -1) ${P}_kernel_stats_singl
 cp $(find $T/stats2 -name "*kernel_stats.csv" | head -1) ${P}_kernel_stats.csv
 cp $T/bench.json ${P}_bench.json
 ls -la ${P}_*
+for n in interior diffuse_box diffuse_box_8passes 10Mtris c4_share_of_8_fast; do [ -f $T/bench_$n.json ] && cp $T/bench_$n.json ${P}_bench_$n.json; done
+ls ${P}_bench_*
