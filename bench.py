@@ -342,7 +342,7 @@ def main():
         rays_per_launch = rays / launches
         # Memory-side traffic and cache-path figures per ray come from the committed PMC profile of this workload (kernels
         # alone on one stream); times are this run's HIP events. Every frac below is a fraction of a ceiling that can bind.
-        prof = pmc_profile(args.tris, args.res, args.scene) if world == 1 else None
+        prof = pmc_profile(args.tris, args.res, args.scene)      # per-ray figures of the 1-GPU profile; a rank's share has the same rays per pixel
         traffic = prof["hbm_bytes_per_ray"] * rays_per_launch if prof else None
         hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
         l2_bytes = prof["l2_request_bytes_per_ray"] * rays_per_launch if prof else None
@@ -374,7 +374,7 @@ def main():
             },
             "units_busy": ({k: prof[k] for k in ("valu_busy", "ta_busy", "td_busy", "td_tc_stall_of_busy", "waves_per_simd", "wait_any",
                                                  "l1_hit", "l2_hit") if k in prof} if prof else None),
-            "limiter": "latency of a trip (pop -> dependent gather -> ~115 VALU -> push) x trips per ray at 8 waves per SIMD; "
+            "limiter": "latency of a trip (pop -> dependent gather -> ~150 VALU + 55 SALU -> push) x 13.8 trips per ray at 8 waves per SIMD; "
                        "no throughput unit is saturated (DESIGN.md section 6)",
             "concurrency": ("shadow kernels run on a second stream beside this kernel: avg_launch_ms includes the time they share the chip")
                            if os.environ.get("SRX_SHADOW_STREAM", "1") != "0" else "one stream",
