@@ -50,7 +50,14 @@ def build(force=False, verbose=True):
         jobs.append((obj, cmd, subprocess.Popen(cmd)))       # one compiler process per translation unit, side by side
     for obj, cmd, proc in jobs:
         if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+            # the per-file -mllvm option is an LLVM-internal one: a compiler that no longer knows it must not break the
+            # build (the kernels are correct either way; the option only saves copies in the traversal loop)
+            plain = [c for c in cmd if c not in sum(EXTRA.values(), [])]
+            if plain != cmd:
+                print("retrying without " + " ".join(sum(EXTRA.values(), [])), flush=True)
+                subprocess.check_call(plain)
+            else:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for obj, _, _ in jobs] + ["-ldl", "-o", OUT]
     if verbose:
         print(" ".join(link), flush=True)
