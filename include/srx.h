@@ -323,6 +323,14 @@ int srx_gltf_get(const srx_gltf* g, const srx_tri** tris, uint32_t* n_tris, cons
  * height; when rgba is not NULL also width * height * 4 bytes (refused if capacity is smaller). Host-only. */
 int srx_image_decode(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint8_t* rgba, size_t capacity);
 
+/* ---- diagnostics (host only; no counterpart in the reference)
+ * How srx_cast_* / the renderer deal n rays to the workgroups of the traversal kernel form with k (8, 4, 2, 1) rays per
+ * octet: full blocks of 8 k rays, then up to tail_blocks blocks each of 4 k, 2 k, ... 8 rays, so that a launch does not
+ * end with a few long waves (csrc/srx_kernels.h). Fills start[] / count[] for up to max_blocks blocks; *n_blocks = the
+ * blocks used, *bound = the grid taken for a launch that may hold up to n rays. Tests check the ranges tile [0, n). */
+int srx_trace_dealing(uint32_t n, int32_t k, uint32_t tail_blocks, uint32_t max_blocks, uint32_t* start, uint32_t* count,
+                      uint32_t* n_blocks, uint32_t* bound);
+
 /* ---- multi-GPU exchange: one process per GPU, scene replicated, tile rows dealt round-robin
  * (srx_trace_pass_interleaved), nothing exchanged on the sample path. What the reference's worker threads hand over in
  * shared memory becomes a collective over RCCL / xGMI (RCCL is loaded at run time; single-GPU use does not need it):

@@ -8,6 +8,7 @@ struct TraceArgs {
     uint32_t n;
     const uint32_t* n_ptr;                 // optional (device): the launch processes min(*n_ptr, n) rays; n sizes the grid (launches
                                            // enqueued before the host knows how many rays the previous kernel produced)
+    uint32_t n_hint;                       // with n_ptr: how many rays the host expects (0 = n); only picks the rays per octet
     GHit* hits;                            // closest form
     float* advanced_org3;                  // optional: o + t*d*0.999f (Core.h:327)
     uint8_t* lit;                          // shadow form, API
@@ -17,7 +18,61 @@ struct TraceArgs {
     uint32_t counter_slot_mask;            // counters are replicated in (mask+1) slots to spread the atomics ...
     uint32_t counter_slot_stride;          // ... slot s starts at counters + s*stride (u64 units); host sums the slots
     int lds_depth;                         // set by srx_launch_trace: stack entries per octet kept in LDS (<= GScene::stack_depth)
+    uint32_t xcd_chunk;                    // set by srx_launch_trace: blocks per chunk of the XCD-aware block -> ray-range map
+    uint32_t tail_blocks;                  // set by srx_launch_trace: blocks per tier of the shrinking tail (srx_trace_tiers), 0 = none
 };
+
+// How the rays of a launch are dealt to its blocks (one wave each). A block of the kernel form with K rays per octet can
+// hold 8 K rays; dealing every block that many makes the launch end with its slowest wave still working through its pool
+// while the chip drains. So the END of the ray range is dealt in smaller portions: tier t = 1, 2, ... log2 K holds up to
+// `tail_blocks` blocks of 8 K >> t rays, the last one 8 rays (one per octet); tier 0 takes everything before them in full
+// blocks. Blocks are dispatched in index order, so the waves that start last have the least to do (guided
+// self-scheduling). Tier boundaries are multiples of a full block counted back from the end of the range rounded up to
+// one, so every tier but the last holds whole blocks. Results do not depend on the dealing.
+// All scalars (no arrays: the kernel keeps them in SGPRs): first ray fr[1..3] and first block fb[1..3] of tiers 1..3
+// (tier 0 starts at ray 0, block 0); returns the number of blocks.
+struct TraceLayout { uint32_t fr1, fr2, fr3, fb1, fb2, fb3, blocks; };
+template <int K>
+__host__ __device__ inline TraceLayout srx_trace_layout(uint32_t n, uint32_t tail_blocks) {
+    constexpr int LEVELS = K == 8 ? 3 : (K == 4 ? 2 : (K == 2 ? 1 : 0));
+    constexpr uint32_t FULL = 8u * K;
+    const uint32_t tb = tail_blocks - tail_blocks % (uint32_t)K;
+    TraceLayout L = {0, 0, 0, 0, 0, 0, 0};
+    const uint64_t end = ((uint64_t)n + FULL - 1) / FULL * FULL;
+    uint64_t at = end;
+    if (LEVELS >= 3) { const uint64_t cap = (uint64_t)tb * (FULL >> 3); at = at > cap ? at - cap : 0; L.fr3 = (uint32_t)at; }
+    if (LEVELS >= 2) { const uint64_t cap = (uint64_t)tb * (FULL >> 2); at = at > cap ? at - cap : 0; L.fr2 = (uint32_t)at; }
+    if (LEVELS >= 1) { const uint64_t cap = (uint64_t)tb * (FULL >> 1); at = at > cap ? at - cap : 0; L.fr1 = (uint32_t)at; }
+    auto between = [n](uint32_t from, uint32_t stop, uint32_t size) {      // blocks of `size` rays over [from, stop), cut at n
+        from = from < n ? from : n; stop = stop < n ? stop : n;
+        return stop > from ? (stop - from + size - 1u) / size : 0u;
+    };
+    const uint32_t e0 = LEVELS >= 1 ? L.fr1 : n, e1 = LEVELS >= 2 ? L.fr2 : n, e2 = LEVELS >= 3 ? L.fr3 : n;
+    L.fb1 = between(0u, e0, FULL);
+    L.fb2 = L.fb1 + (LEVELS >= 1 ? between(L.fr1, e1, FULL >> 1) : 0u);
+    L.fb3 = L.fb2 + (LEVELS >= 2 ? between(L.fr2, e2, FULL >> 2) : 0u);
+    L.blocks = L.fb3 + (LEVELS >= 3 ? between(L.fr3, n, FULL >> 3) : 0u);
+    return L;
+}
+// the rays of logical block b: [start, start + count)
+template <int K>
+__host__ __device__ inline void srx_trace_block_range(const TraceLayout& L, uint32_t n, uint32_t b, uint32_t& start, uint32_t& count) {
+    constexpr int LEVELS = K == 8 ? 3 : (K == 4 ? 2 : (K == 2 ? 1 : 0));
+    constexpr uint32_t FULL = 8u * K;
+    uint32_t size = FULL, first_ray = 0, first_block = 0;
+    if (LEVELS >= 1 && b >= L.fb1) { size = FULL >> 1; first_ray = L.fr1; first_block = L.fb1; }
+    if (LEVELS >= 2 && b >= L.fb2) { size = FULL >> 2; first_ray = L.fr2; first_block = L.fb2; }
+    if (LEVELS >= 3 && b >= L.fb3) { size = FULL >> 3; first_ray = L.fr3; first_block = L.fb3; }
+    start = first_ray + (b - first_block) * size;
+    count = (b < L.blocks && start < n) ? ((n - start) < size ? (n - start) : size) : 0u;
+}
+// an upper bound of the block count for every ray count <= n (the count itself dips by up to K - 1 each time the rounded
+// end moves): what a grid must have when the launch reads its ray count on the device
+template <int K>
+__host__ __device__ inline uint32_t srx_trace_blocks_bound(uint32_t n, uint32_t tail_blocks) {
+    const uint64_t end = ((uint64_t)n + 8u * K - 1) / (8u * K) * (8u * K);
+    return srx_trace_layout<K>((uint32_t)(end > 0xFFFFFFFFull ? 0xFFFFFFFFull : end), tail_blocks).blocks;
+}
 
 // mode 0: closest hit; 1: shadow (API form, writes lit[]); 2: shadow (renderer queue form, adds lit contributions)
 extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& a, hipStream_t stream);

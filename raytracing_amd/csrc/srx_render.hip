@@ -196,14 +196,14 @@ int join_shadows(srx_renderer* r) {
 // n_ptr (device, optional): the batch holds min(*n_ptr, n) rays, n only sizes the grids. The children go to `out`, their
 // number and the number of shadow rays to `dc` (device). q = the shadow queue the shade kernel fills.
 int launch_batch(srx_renderer* r, int gen, const GRay* in, uint32_t n, const uint32_t* n_ptr, GRay* out, DeviceCounts* dc, int q,
-                 bool shadow_count_on_device, uint32_t n_shadow_known, hipEvent_t shade_done) {
+                 bool shadow_count_on_device, uint32_t n_hint, hipEvent_t shade_done) {
     const GScene& g = r->scene->g;
     size_t ts;
     TraceArgs t;
     std::memset(&t, 0, sizeof(t));
     t.org = &in->ox; t.org_stride = sizeof(GRay) / 4;
     t.dir = &in->dx; t.dir_stride = sizeof(GRay) / 4;
-    t.n = n; t.n_ptr = n_ptr;
+    t.n = n; t.n_ptr = n_ptr; t.n_hint = n_hint;
     t.hits = r->hits;
     t.counters = r->d_counters + CTR_NODES; t.counter_slot_mask = CTR_SLOTS - 1; t.counter_slot_stride = CTR_COUNT;
     if (t_begin(r, T_TRACE, r->stream, &ts)) return 1;
@@ -221,7 +221,6 @@ int launch_batch(srx_renderer* r, int gen, const GRay* in, uint32_t n, const uin
     if (t_end(r, ts, r->stream)) return 1;
     r->acc.trace_launches++; r->acc.shade_launches++;
     if (!shadow_count_on_device) return 0;          // the caller launches the shadow kernel once it has the count
-    (void)n_shadow_known;
     if (g.n_suns) {
         // shadow rays of this batch, counted on the device: grid for the most there can be
         SRX_HIP(hipEventRecord(shade_done, r->stream));
@@ -230,7 +229,7 @@ int launch_batch(srx_renderer* r, int gen, const GRay* in, uint32_t n, const uin
         TraceArgs sh;
         std::memset(&sh, 0, sizeof(sh));
         sh.org = &r->shadow_q[q][0].ox; sh.org_stride = sizeof(GShadow) / 4;
-        sh.n = n * g.n_suns; sh.n_ptr = &dc->shadow_count;
+        sh.n = n * g.n_suns; sh.n_ptr = &dc->shadow_count; sh.n_hint = n_hint * g.n_suns;
         sh.shadow_q = r->shadow_q[q]; sh.sample3 = r->sample3;
         sh.counters = r->d_counters + CTR_SNODES; sh.counter_slot_mask = CTR_SLOTS - 1; sh.counter_slot_stride = CTR_COUNT;
         if (t_begin(r, T_SHADOW, ss, &ts)) return 1;
@@ -258,14 +257,22 @@ int process_chain(srx_renderer* r, int gen, uint64_t begin, uint64_t n) {
     const GRay* in = r->rays + begin;
     const uint32_t* n_ptr = nullptr;
     uint32_t bound = (uint32_t)n;
+    // What the host expects link k to hold (it knows the counts up to link k - 2): the last known count shrunk by the
+    // last known ratio once per link since. Only the form of the traversal kernel depends on it (rays per octet: a launch
+    // that turns out small should not run a few long waves); the grid is sized for `bound`.
+    double known = (double)n, ratio = 1.0;
+    int known_at = 0;
+    static const bool chain_log = getenv("SRX_CHAIN_LOG") != nullptr;
     int used = 0;
     for (int k = 0; k < links; k++) {
         const int q = r->shadow_flip;
         if (retire_shadow(r, q, false)) return 1;            // the shadow kernel that read queue q: the main stream waits on the device
-        if (launch_batch(r, gen + k, in, bound, n_ptr, region[k & 1], r->d_ring + k, q, true, 0, r->ring_ev[k])) return 1;
+        const uint32_t hint = (uint32_t)std::max(1.0, std::min((double)bound, known * std::pow(ratio, k - known_at)));
+        if (launch_batch(r, gen + k, in, bound, n_ptr, region[k & 1], r->d_ring + k, q, true, hint, r->ring_ev[k])) return 1;
         SRX_HIP(hipMemcpyAsync(r->h_ring + k, r->d_ring + k, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
-        if (!g.n_suns) SRX_HIP(hipEventRecord(r->ring_ev[k], r->stream));
-        else { SRX_HIP(hipEventRecord(r->ring_ev[k], r->stream)); }
+        // (launch_batch recorded the same event after the shade kernel for the shadow stream to wait on; that wait was
+        // enqueued then and keeps referring to that record. This record, after the copy, is the one the host waits for.)
+        SRX_HIP(hipEventRecord(r->ring_ev[k], r->stream));
         used = k + 1;
         if (gen + k >= g.max_generations) break;              // Core.h:473: this generation queued nothing
         // The host stays at most two links ahead of the device: before link k + 1 is enqueued it has the count of link
@@ -276,12 +283,19 @@ int process_chain(srx_renderer* r, int gen, uint64_t begin, uint64_t n) {
             const uint32_t c = r->h_ring[k - 1].out_count;    // rays of link k; link k + 1 has no more
             if (c == 0) break;
             bound = std::min(bound, c);
+            ratio = std::min(1.0, (double)c / std::max(1.0, known));
+            known = (double)c; known_at = k;
         }
         in = region[k & 1];
         n_ptr = &r->d_ring[k].out_count;
     }
     SRX_HIP(hipStreamSynchronize(r->stream));
     uint64_t rays = n;
+    if (chain_log) {
+        std::fprintf(stderr, "srx chain gen %d: %llu", gen, (unsigned long long)n);
+        for (int k = 0; k < used; k++) std::fprintf(stderr, " -> %u (+%u shadow)", r->h_ring[k].out_count, r->h_ring[k].shadow_count);
+        std::fprintf(stderr, "\n");
+    }
     for (int k = 0; k < used; k++) {
         const uint64_t c = r->h_ring[k].out_count, sh = r->h_ring[k].shadow_count;
         if (c > n || sh > n * g.n_suns) SRX_FAIL("srx: internal error, a chained generation grew");

@@ -15,6 +15,8 @@
 // Bound: HBM/L2 gather bandwidth + latency (no MFMA work here); see DESIGN.md.
 #include "srx_kernels.h"
 #include <cstdlib>
+#include <type_traits>
+#include <algorithm>
 
 // One wave per block: a finished wave frees its slot at once instead of waiting for three block mates whose rays
 // run longer (measured: 256 -> 64 threads per block = -5 % kernel time on incoherent rays).
@@ -178,7 +180,6 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, co
 // moves to the wave's overflow area in memory when a push might not fit, and comes back when the LDS part runs empty.
 template <int MODE, int K, bool SPILL>
 __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArgs a) {
-    constexpr uint32_t SRX_RAYS_PER_BLOCK = SRX_OCTETS_PER_BLOCK * K;
     // LDS: traversal stack [depth][octets of the block] of (tmin bits << 32 | link), then one 16-B best-hit record per octet
     extern __shared__ unsigned long long s_mem[];
     unsigned long long* const s_stack = s_mem;
@@ -196,12 +197,31 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     // (the grid may have been sized for more rays than there are, a.n_ptr: the map is made over the blocks that have
     // rays, so that they are still dealt evenly over the XCDs; the others leave at once)
     const uint32_t n_rays = a.n_ptr ? min(*a.n_ptr, a.n) : a.n;
-    const uint32_t nblk = a.n_ptr ? min(gridDim.x, ((n_rays + SRX_RAYS_PER_BLOCK - 1u) / SRX_RAYS_PER_BLOCK + 7u) & ~7u) : gridDim.x;
+    // the dealing of the rays to the blocks (srx_trace_layout: full blocks, then a tail of ever smaller ones), made over the
+    // rays there are; the grid was sized for a.n, blocks beyond the dealing leave at once
+    const TraceLayout layout = srx_trace_layout<K>(n_rays, a.tail_blocks);
+    const uint32_t nblk_used = layout.blocks;
+    const uint32_t nblk = min(gridDim.x, (nblk_used + 7u) & ~7u);
     if (blockIdx.x >= nblk) return;
     const uint32_t per_xcd = (nblk + 7u) >> 3;
-    const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    // ray j of this octet; the block's rays are contiguous in the queue
-    const uint32_t ray0 = lblock * SRX_RAYS_PER_BLOCK + oct;
+    uint32_t lblock;
+    {
+        // XCD x takes chunks x, x + 8, x + 16, ... of `xcd_chunk` consecutive blocks (consecutive rays: neighbours in the
+        // image or children of neighbours, which walk the same part of the tree and share that XCD's L2), so all eight
+        // XCDs advance through the queue together. One contiguous eighth per XCD (the first form of this map) left the
+        // XCDs with unequal work: image regions differ in cost and the queue is in image order.
+        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, C = a.xcd_chunk;
+        const uint32_t full = per_xcd / C, rem = per_xcd - full * C;
+        lblock = j < full * C ? ((j / C) * 8u + x) * C + j % C : full * C * 8u + x * rem + (j - full * C);
+    }
+    // this block's rays: [block_start, block_start + block_rays), contiguous in the queue
+    uint32_t block_start = 0;
+    int block_rays = 0;
+    {
+        uint32_t cnt;
+        srx_trace_block_range<K>(layout, n_rays, lblock, block_start, cnt);
+        block_rays = (int)cnt;
+    }
     float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {d, o.x}, {o.yz, inv.xy}, {inv.z, fused}
     float2* const s_pt = (float2*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening, quantised direction (bits)
     uint32_t* const s_spilled = (uint32_t*)(s_pt + K * SRX_OCTETS_PER_BLOCK);   // [octets]: entries parked in memory (SPILL)
@@ -210,8 +230,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     // ---- set-up of all K rays of the octet at once: lane `sub` prepares ray `sub`
     bool fast;
     {
-        const uint32_t myray = ray0 + (uint32_t)sub * SRX_OCTETS_PER_BLOCK;
-        const bool mine = sub < K && lblock < nblk && myray < n_rays;
+        const int myj = sub * SRX_OCTETS_PER_BLOCK + oct;       // lane `sub` of octet `oct` prepares the block's ray myj
+        const uint32_t myray = block_start + (uint32_t)myj;
+        const bool mine = sub < K && myj < block_rays;
         f3 so, sd;
         if (mine) {
             const float* po = a.org + (size_t)myray * a.org_stride;
@@ -252,11 +273,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     }
     // the block's rays that exist are j = 0 .. block_rays-1 (ray j was set up by lane j / 8 of octet j % 8); octet o starts
     // with ray o, `next_j` (wave-uniform) is the first ray no octet has taken yet
-    int block_rays = 0;
-    if (lblock < nblk && lblock * SRX_RAYS_PER_BLOCK < n_rays) block_rays = (int)min(SRX_RAYS_PER_BLOCK, n_rays - lblock * SRX_RAYS_PER_BLOCK);
     int cur = oct < block_rays ? oct : -1;   // the ray this octet works on, -1 = none
     int next_j = SRX_OCTETS_PER_BLOCK;
-    uint32_t ray = ray0;
+    uint32_t ray = block_start + (uint32_t)oct;
     const bool live = cur >= 0;
     __builtin_amdgcn_wave_barrier();
 
@@ -481,7 +500,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                     cur = -1;
                     if (j < block_rays) {
                         cur = j;
-                        ray = lblock * SRX_OCTETS_PER_BLOCK * K + (uint32_t)j;
+                        ray = block_start + (uint32_t)j;
                         load_ray_j(j);
                         best_t = SRX_MISS_DISTANCE;
                         sp = 0;
@@ -536,7 +555,8 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
         int k = SRX_RAYS_PER_OCTET_MAX;
         while (k > 1 && trace_lds_bytes(lds_depth, k, spill_form) > lds_budget) k >>= 1;
         static const uint64_t rounds8 = [] { const char* e = getenv("SRX_K8_ROUNDS"); return (uint64_t)(e ? atoi(e) : 4); }();
-        while (k > 1 && (uint64_t)a.n < (k == 8 ? rounds8 : 1ull) * 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
+        const uint64_t expected = (a.n_ptr && a.n_hint) ? std::min<uint64_t>(a.n_hint, a.n) : a.n;
+        while (k > 1 && expected < (k == 8 ? rounds8 : 1ull) * 8192ull * SRX_OCTETS_PER_BLOCK * (uint64_t)k) k >>= 1;
         return k;
     };
     // Plain form (the tree's whole worst-case stack in LDS) or SPILL form (SRX_SPILL_LDS_DEPTH entries in LDS, the
@@ -556,10 +576,18 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
         k = rays_per_octet(depth, spill);
     }
     a.lds_depth = depth;
+    // blocks per chunk of the XCD map (swept 8-512: flat, +3.8 % against one contiguous eighth per XCD; SRX_XCD_CHUNK=0 = that form)
+    static const uint32_t xcd_chunk = [] { const char* e = getenv("SRX_XCD_CHUNK"); const int v = e ? atoi(e) : 32; return (uint32_t)(v > 0 ? v : 0); }();
+    a.xcd_chunk = xcd_chunk ? xcd_chunk : 0x7fffffffu;
     static const int forced = [] { const char* e = getenv("SRX_RAYS_PER_OCTET"); return e ? atoi(e) : 0; }();   // experiments
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) k = forced;
-    const uint32_t rays_per_block = SRX_OCTETS_PER_BLOCK * (uint32_t)k;
-    uint32_t blocks = (a.n + rays_per_block - 1) / rays_per_block;
+    // blocks per tier of the shrinking tail (swept 0-32 768, SRX_TAIL_BLOCKS: the closed diffuse box, whose passes are a handful of
+    // launches with nothing beside them, gains 3 / 6 / 7 % at 2 048 / 8 192 / 16 384; the atrium, whose tails the shadow kernels on the
+    // second stream fill anyway, loses 0.2 / 0.6 / 0.7 %)
+    static const uint32_t tail_blocks = [] { const char* e = getenv("SRX_TAIL_BLOCKS"); return (uint32_t)(e ? atoi(e) : 4096); }();
+    a.tail_blocks = tail_blocks;
+    uint32_t blocks = k == 8 ? srx_trace_blocks_bound<8>(a.n, tail_blocks) : k == 4 ? srx_trace_blocks_bound<4>(a.n, tail_blocks)
+                    : k == 2 ? srx_trace_blocks_bound<2>(a.n, tail_blocks) : srx_trace_blocks_bound<1>(a.n, tail_blocks);
     blocks = (blocks + 7u) & ~7u;   // multiple of 8 so the XCD map covers every logical block exactly once
     const size_t lds = trace_lds_bytes(depth, k, spill);
     if (spill) {
@@ -574,4 +602,24 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
         else launch_k<1, false>(mode, blocks, lds, sc, a, stream);
     }
     return hipGetLastError();
+}
+
+// Diagnostics (host only, tests/test_host_cpu.py): the dealing of n rays to the blocks of the kernel form with k rays per octet,
+// exactly as the kernel computes it. start / count take up to max_blocks entries; *n_blocks = blocks used, *bound = the
+// grid size the launcher takes for a launch of up to n rays.
+extern "C" int srx_trace_dealing(uint32_t n, int32_t k, uint32_t tail_blocks, uint32_t max_blocks, uint32_t* start, uint32_t* count,
+                                 uint32_t* n_blocks, uint32_t* bound) {
+    auto run = [&](auto tag) {
+        constexpr int K = decltype(tag)::value;
+        const TraceLayout L = srx_trace_layout<K>(n, tail_blocks);
+        if (n_blocks) *n_blocks = L.blocks;
+        if (bound) *bound = srx_trace_blocks_bound<K>(n, tail_blocks);
+        for (uint32_t b = 0; b < L.blocks && b < max_blocks && start && count; b++) srx_trace_block_range<K>(L, n, b, start[b], count[b]);
+    };
+    if (k == 8) run(std::integral_constant<int, 8>());
+    else if (k == 4) run(std::integral_constant<int, 4>());
+    else if (k == 2) run(std::integral_constant<int, 2>());
+    else if (k == 1) run(std::integral_constant<int, 1>());
+    else return 1;
+    return 0;
 }

@@ -117,3 +117,38 @@ def test_parallel_packager_is_thread_count_independent(monkeypatch):
     S = sro.OracleScene(desc, build_tables=False)
     n, p, t = S.packaged()
     assert out[0] == (n.tobytes(), p.tobytes(), t.tobytes())
+
+
+def test_trace_dealing_tiles_the_ray_range():
+    """The traversal kernel deals its rays to blocks in full portions followed by a shrinking tail (srx_trace_layout in
+    csrc/srx_kernels.h, the same function on host and device). Whatever the sizes: the block ranges tile [0, n) in order,
+    no block is empty, and the grid bound the launcher takes covers every smaller ray count (launches that read their count
+    on the device)."""
+    import ctypes as C
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    sizes = [0, 1, 7, 8, 9, 63, 64, 65, 511, 512, 513, 4095, 65536, 100001, 2073600] + [int(x) for x in rng.integers(1, 3_000_000, 12)]
+    for k in (1, 2, 4, 8):
+        for tail in (0, 1, 5, 8, 24, 8192):
+            for n in sizes:
+                nb, bound = C.c_uint32(), C.c_uint32()
+                assert L.srx_trace_dealing(C.c_uint32(n), C.c_int32(k), C.c_uint32(tail), C.c_uint32(0), None, None, C.byref(nb), C.byref(bound)) == 0
+                start, count = np.zeros(nb.value, np.uint32), np.zeros(nb.value, np.uint32)
+                p = lambda a: a.ctypes.data_as(C.c_void_p)
+                L.srx_trace_dealing(C.c_uint32(n), C.c_int32(k), C.c_uint32(tail), C.c_uint32(nb.value), p(start), p(count), None, None)
+                assert (count > 0).all() and (count <= 8 * k).all()
+                assert np.array_equal(start.astype(np.int64), np.concatenate([[0], np.cumsum(count.astype(np.int64))[:-1]]).astype(np.int64)[:len(start)]) if nb.value else n == 0
+                assert int(count.sum()) == n
+                assert nb.value <= bound.value
+                if tail and nb.value > 1:
+                    assert (np.diff(count.astype(np.int64)[:-1]) <= 0).all()        # sizes never grow along the range (last block may be partial)
+    for k in (2, 4, 8):                                   # the bound holds for every smaller count
+        for tail in (0, 3, 8, 16):
+            for n in list(range(0, 700)) + [5000, 5001, 5063, 5064]:
+                bound = C.c_uint32()
+                L.srx_trace_dealing(C.c_uint32(n), C.c_int32(k), C.c_uint32(tail), C.c_uint32(0), None, None, None, C.byref(bound))
+                for m in range(max(0, n - 130), n + 1):
+                    nb = C.c_uint32()
+                    L.srx_trace_dealing(C.c_uint32(m), C.c_int32(k), C.c_uint32(tail), C.c_uint32(0), None, None, C.byref(nb), None)
+                    assert nb.value <= bound.value, (k, tail, n, m)
+    assert L.srx_trace_dealing(C.c_uint32(10), C.c_int32(3), C.c_uint32(0), C.c_uint32(0), None, None, None, None) != 0
