@@ -2,7 +2,7 @@
 # diffuse box (C5): Mrays/s against the number of sample passes that share the launches
 mkdir -p gpurun_out
 for b in 1 2 4 8; do
-  timeout -k 10 200 python bench.py --scene diffuse_box --no-cpu-baseline --no-fast-tree --steps 16 --warmup 8 --passes-per-call $b > gpurun_out/boxppc_$b.json 2> gpurun_out/boxppc_$b.err || { echo "B=$b FAILED"; tail -3 gpurun_out/boxppc_$b.err; exit 1; }
+  timeout -k 10 200 python bench.py --scene diffuse_box --tris 50000 --no-cpu-baseline --no-fast-tree --steps 16 --warmup 8 --passes-per-call $b > gpurun_out/boxppc_$b.json 2> gpurun_out/boxppc_$b.err || { echo "B=$b FAILED"; tail -3 gpurun_out/boxppc_$b.err; exit 1; }
   python - $b <<'PY'
 import json,sys
 b=sys.argv[1]; a=json.load(open(f'gpurun_out/boxppc_{b}.json')); r=a['roofline']
