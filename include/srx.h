@@ -330,6 +330,9 @@ int srx_image_decode(const uint8_t* data, size_t n, uint32_t* width, uint32_t* h
  * blocks used, *bound = the grid taken for a launch that may hold up to n rays. Tests check the ranges tile [0, n). */
 int srx_trace_dealing(uint32_t n, int32_t k, uint32_t tail_blocks, uint32_t max_blocks, uint32_t* start, uint32_t* count,
                       uint32_t* n_blocks, uint32_t* bound);
+/* ... and which logical block each hardware block of a launch of nblk (a multiple of 8) blocks takes: XCD b % 8 works through
+ * interleaved chunks of `chunk` logical blocks. logical[nblk]; a permutation of 0 .. nblk - 1. */
+int srx_trace_xcd_map(uint32_t nblk, uint32_t chunk, uint32_t* logical);
 
 /* ---- multi-GPU exchange: one process per GPU, scene replicated, tile rows dealt round-robin
  * (srx_trace_pass_interleaved), nothing exchanged on the sample path. What the reference's worker threads hand over in

@@ -20,7 +20,7 @@ EXPORTS = [
     "srx_trace_pass", "srx_trace_pass_interleaved", "srx_trace_passes_interleaved", "srx_trace_pass_adaptive", "srx_process_rays", "srx_camera_rays", "srx_camera_rays_xorgen", "srx_xorgen_stream",
     "srx_noise_create", "srx_noise_destroy", "srx_noise_set_option", "srx_noise_error_map", "srx_noise_analyze", "srx_noise_regions", "srx_noise_priorities",
     "srx_buffer_create", "srx_buffer_destroy", "srx_buffer_read", "srx_buffer_write", "srx_buffer_clear", "srx_post_process", "srx_write_raw", "srx_read_raw", "srx_write_png",
-    "srx_gltf_load", "srx_gltf_destroy", "srx_gltf_get", "srx_image_decode", "srx_trace_dealing",
+    "srx_gltf_load", "srx_gltf_destroy", "srx_gltf_get", "srx_image_decode", "srx_trace_dealing", "srx_trace_xcd_map",
     "srx_group_unique_id", "srx_group_create", "srx_group_destroy", "srx_group_rank", "srx_group_gather_framebuffer",
     "srx_group_allgather_rows", "srx_group_allreduce", "srx_rows_slot_floats", "srx_rows_pack", "srx_rows_unpack",
 ]

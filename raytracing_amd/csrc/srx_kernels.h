@@ -74,6 +74,15 @@ __host__ __device__ inline uint32_t srx_trace_blocks_bound(uint32_t n, uint32_t 
     return srx_trace_layout<K>((uint32_t)(end > 0xFFFFFFFFull ? 0xFFFFFFFFull : end), tail_blocks).blocks;
 }
 
+// XCD-aware placement: hardware block b runs on XCD b % 8; XCD x works through chunks x, x + 8, x + 16, ... of `chunk`
+// consecutive logical blocks (what is left over when the blocks per XCD are not a multiple of `chunk` is dealt as one
+// shorter chunk per XCD at the end). nblk is a multiple of 8; a bijection of [0, nblk).
+__host__ __device__ inline uint32_t srx_xcd_logical_block(uint32_t b, uint32_t nblk, uint32_t chunk) {
+    const uint32_t per_xcd = nblk >> 3, x = b & 7u, j = b >> 3;
+    const uint32_t full = per_xcd / chunk, rem = per_xcd - full * chunk;
+    return j < full * chunk ? ((j / chunk) * 8u + x) * chunk + j % chunk : full * chunk * 8u + x * rem + (j - full * chunk);
+}
+
 // mode 0: closest hit; 1: shadow (API form, writes lit[]); 2: shadow (renderer queue form, adds lit contributions)
 extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& a, hipStream_t stream);
 

@@ -203,17 +203,11 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const uint32_t nblk_used = layout.blocks;
     const uint32_t nblk = min(gridDim.x, (nblk_used + 7u) & ~7u);
     if (blockIdx.x >= nblk) return;
-    const uint32_t per_xcd = (nblk + 7u) >> 3;
-    uint32_t lblock;
-    {
-        // XCD x takes chunks x, x + 8, x + 16, ... of `xcd_chunk` consecutive blocks (consecutive rays: neighbours in the
-        // image or children of neighbours, which walk the same part of the tree and share that XCD's L2), so all eight
-        // XCDs advance through the queue together. One contiguous eighth per XCD (the first form of this map) left the
-        // XCDs with unequal work: image regions differ in cost and the queue is in image order.
-        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, C = a.xcd_chunk;
-        const uint32_t full = per_xcd / C, rem = per_xcd - full * C;
-        lblock = j < full * C ? ((j / C) * 8u + x) * C + j % C : full * C * 8u + x * rem + (j - full * C);
-    }
+    // XCD x takes chunks x, x + 8, x + 16, ... of `xcd_chunk` consecutive blocks (consecutive rays: neighbours in the image or
+    // children of neighbours, which walk the same part of the tree and share that XCD's L2), so all eight XCDs advance
+    // through the queue together. One contiguous eighth per XCD (the first form of this map) left the XCDs with unequal
+    // work: image regions differ in cost and the queue is in image order.
+    const uint32_t lblock = srx_xcd_logical_block(blockIdx.x, nblk, a.xcd_chunk);
     // this block's rays: [block_start, block_start + block_rays), contiguous in the queue
     uint32_t block_start = 0;
     int block_rays = 0;
@@ -607,6 +601,11 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
 // Diagnostics (host only, tests/test_host_cpu.py): the dealing of n rays to the blocks of the kernel form with k rays per octet,
 // exactly as the kernel computes it. start / count take up to max_blocks entries; *n_blocks = blocks used, *bound = the
 // grid size the launcher takes for a launch of up to n rays.
+extern "C" int srx_trace_xcd_map(uint32_t nblk, uint32_t chunk, uint32_t* logical) {
+    if ((nblk & 7u) || chunk == 0 || !logical) return 1;
+    for (uint32_t b = 0; b < nblk; b++) logical[b] = srx_xcd_logical_block(b, nblk, chunk);
+    return 0;
+}
 extern "C" int srx_trace_dealing(uint32_t n, int32_t k, uint32_t tail_blocks, uint32_t max_blocks, uint32_t* start, uint32_t* count,
                                  uint32_t* n_blocks, uint32_t* bound) {
     auto run = [&](auto tag) {

@@ -152,3 +152,23 @@ def test_trace_dealing_tiles_the_ray_range():
                     L.srx_trace_dealing(C.c_uint32(m), C.c_int32(k), C.c_uint32(tail), C.c_uint32(0), None, None, C.byref(nb), None)
                     assert nb.value <= bound.value, (k, tail, n, m)
     assert L.srx_trace_dealing(C.c_uint32(10), C.c_int32(3), C.c_uint32(0), C.c_uint32(0), None, None, None, None) != 0
+
+
+def test_xcd_map_is_a_permutation_that_keeps_chunks_on_one_xcd():
+    import ctypes as C
+    L = _lib.lib()
+    for nblk in (8, 16, 64, 72, 1000 * 8, 4104, 25232 + 8):
+        for chunk in (1, 3, 8, 32, 512, 0x7fffffff):
+            out = np.zeros(nblk, np.uint32)
+            assert L.srx_trace_xcd_map(C.c_uint32(nblk), C.c_uint32(chunk), out.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(np.sort(out), np.arange(nblk, dtype=np.uint32)), (nblk, chunk)
+            per = nblk // 8
+            full = (per // chunk) * chunk * 8                       # logical blocks that lie in whole chunks
+            lb = out.astype(np.int64)
+            hw_xcd = np.arange(nblk) % 8
+            inside = lb < full
+            assert np.array_equal((lb[inside] // chunk) % 8, hw_xcd[inside])     # chunk c runs on XCD c % 8
+            # each XCD sees its logical blocks in ascending order (blocks are dispatched in index order)
+            for x in range(8):
+                assert (np.diff(lb[hw_xcd == x]) > 0).all()
+    assert L.srx_trace_xcd_map(C.c_uint32(12), C.c_uint32(4), np.zeros(12, np.uint32).ctypes.data_as(C.c_void_p)) != 0
