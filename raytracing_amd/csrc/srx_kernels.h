@@ -85,6 +85,7 @@ __host__ __device__ inline uint32_t srx_xcd_logical_block(uint32_t b, uint32_t n
 
 // mode 0: closest hit; 1: shadow (API form, writes lit[]); 2: shadow (renderer queue form, adds lit contributions)
 extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& a, hipStream_t stream);
+extern "C" int srx_trace_selftest();   // 0 = the cross-lane rank / min code gives the defined results on the current device
 
 // == srx_camera (include/srx.h), Camera.h:32-140
 struct GCamera {

@@ -62,7 +62,16 @@ extern "C" int srx_init(int device) {
     if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
         SRX_FAIL(std::string("srx_init: kernels are built for gfx950 only, device is ") + p.gcnArchName);
     StaticScratch* sp = nullptr;
-    return static_scratch_for(device, &sp);
+    if (static_scratch_for(device, &sp)) return 1;
+    // once per device: the traversal kernel's hand-written cross-lane code against its definition (csrc/srx_trace.hip)
+    static std::mutex mu;
+    static std::vector<int> tested;
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(tested.begin(), tested.end(), device) == tested.end()) {
+        if (srx_trace_selftest()) return 1;
+        tested.push_back(device);
+    }
+    return 0;
 }
 
 namespace {

@@ -15,6 +15,8 @@
 // Bound: HBM/L2 gather bandwidth + latency (no MFMA work here); see DESIGN.md.
 #include "srx_kernels.h"
 #include <cstdlib>
+#include <vector>
+#include <string>
 #include <type_traits>
 #include <algorithm>
 
@@ -596,6 +598,56 @@ extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceAr
         else launch_k<1, false>(mode, blocks, lds, sc, a, stream);
     }
     return hipGetLastError();
+}
+
+// ---- self-test of the hand-written cross-lane code (srx_init, once per device)
+// octet_rank_u32 is inline asm with the gfx950 wait states between a VALU write of VCC / of a DPP source and its read put
+// in by hand (the assembler is not told about them inside an asm block), and octet_min_u32 leans on DPP controls: a
+// compiler that schedules around the block differently, or a different chip, must not silently give wrong child orders.
+// 256 octets of pseudo-random distinct keys (and the corner cases: equal high bits, 0xFFFFFFFF fillers) through both,
+// compared on the host with the definition: rank = number of smaller keys in the octet, min = the smallest.
+__global__ __launch_bounds__(64) void k_octet_selftest(const uint32_t* keys, uint32_t* rank_out, uint32_t* min_out) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t k = keys[i];
+    rank_out[i] = (uint32_t)octet_rank_u32(k);
+    min_out[i] = octet_min_u32(k);
+}
+void srx_set_error(const std::string& s);   // srx_scene.hip
+extern "C" int srx_trace_selftest() {
+    const uint32_t n = 256 * 8;
+    std::vector<uint32_t> keys(n), want_rank(n), want_min(n), got_rank(n), got_min(n);
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    auto next = [&] { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return (uint32_t)(state >> 24); };
+    for (uint32_t o = 0; o < n / 8; o++) {
+        const int fillers = (int)(o % 9);                          // 0..8 lanes hold the "invalid" key
+        for (uint32_t l = 0; l < 8; l++) {
+            uint32_t k = next();
+            if (o % 5 == 1) k = (k & 0xFFu) << 3;                  // small keys
+            if (o % 5 == 2) k |= 0xFFFFFF00u;                      // keys that differ in the low byte only
+            k = (k & ~7u) | l;                                     // distinct, as the traversal's keys are (lane id in the low bits)
+            if ((int)l < fillers && o % 2) k = 0xFFFFFFFFu;        // invalid lanes sort last (equal keys: rank counts strictly smaller ones)
+            keys[o * 8 + l] = k;
+        }
+        for (uint32_t l = 0; l < 8; l++) {
+            uint32_t r = 0, m = 0xFFFFFFFFu;
+            for (uint32_t j = 0; j < 8; j++) { r += keys[o * 8 + j] < keys[o * 8 + l]; m = std::min(m, keys[o * 8 + j]); }
+            want_rank[o * 8 + l] = r; want_min[o * 8 + l] = m;
+        }
+    }
+    uint32_t* d = nullptr;
+    if (hipMalloc((void**)&d, 3 * n * sizeof(uint32_t)) != hipSuccess) { srx_set_error("srx_init: self-test allocation failed"); return 1; }
+    hipError_t e = hipMemcpy(d, keys.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_octet_selftest, dim3(n / 64), dim3(64), 0, 0, d, d + n, d + 2 * n); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(got_rank.data(), d + n, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(got_min.data(), d + 2 * n, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) { srx_set_error(std::string("srx_init: self-test: ") + hipGetErrorString(e)); return 1; }
+    if (got_rank != want_rank || got_min != want_min) {
+        srx_set_error("srx_init: the cross-lane rank / min code of the traversal kernel gives wrong results on this device with this build "
+                      "(hand-placed wait states in csrc/srx_trace.hip octet_rank_u32): refusing to run");
+        return 1;
+    }
+    return 0;
 }
 
 // Diagnostics (host only, tests/test_host_cpu.py): the dealing of n rays to the blocks of the kernel form with k rays per octet,
