@@ -105,6 +105,24 @@ def _adversarial_rays(desc, seed, n):
     dist = ext * 10.0 ** rng.uniform(-2, 0.5, (n, 1))
     out["edge_on"] = ((X - d * dist).astype(np.float32), d.astype(np.float32))
 
+    # ---- the same construction aimed at the filter's own margins: tilts around the guard's threshold (sin(gamma)|cos(phi)| = 1/80,
+    # i.e. 5e-3 .. 0.1 rad out of the plane) and gaps of 1e-5 .. 3e-3 of the distance flown, around the relative pad (5e-4)
+    k = rng.integers(0, m, n // 2)
+    p1, e1, e2 = P[k, 0], P[k, 1] - P[k, 0], P[k, 2] - P[k, 0]
+    nrm = np.cross(e1, e2)
+    nrm = nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    edge_dir = e1 / np.maximum(np.linalg.norm(e1, axis=1, keepdims=True), 1e-300)
+    outward = np.cross(edge_dir, nrm)
+    outward *= -np.sign(np.sum(outward * e2, 1, keepdims=True))
+    dist = ext * 10.0 ** rng.uniform(-1.5, 0.7, (n // 2, 1))
+    gap = dist * 10.0 ** rng.uniform(-5, -2.5, (n // 2, 1))
+    X = p1 + e1 * rng.uniform(0.0, 1.0, (n // 2, 1)) + outward * gap
+    phi = rng.uniform(0, 2 * np.pi, (n // 2, 1))
+    tilt = 10.0 ** rng.uniform(np.log10(5e-3), -1, (n // 2, 1)) * rng.choice([-1.0, 1.0], (n // 2, 1))
+    d = edge_dir * np.cos(phi) + outward * np.sin(phi) + nrm * tilt
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out["near_threshold"] = ((X - d * dist).astype(np.float32), d.astype(np.float32))
+
     # ---- rays that START on a triangle's plane (tvec in the plane) and leave at a shallow angle
     k = rng.integers(0, m, n // 2)
     p1, e1, e2 = P[k, 0], P[k, 1] - P[k, 0], P[k, 2] - P[k, 0]
