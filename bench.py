@@ -8,9 +8,13 @@ Rays = process_ray invocations (primary + every bounce generation), the referenc
 (SceneManager.h:83-90); shadow rays are reported beside it. The scene, tables and framebuffers are resident
 in HBM before the timed region starts.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the frame is sharded by tile rows
-dealt round-robin over the ranks, with the scene replicated (strong scaling, total work fixed); no collective on the data path, one
-framebuffer all-gather over RCCL at the end of the timed region.
+Multi-GPU (one rank per GPU): the frame is sharded by tile rows dealt round-robin over the ranks, with the scene
+replicated (strong scaling, total work fixed); no collective on the data path, one framebuffer all-gather over RCCL at
+the end of the timed region. `python3 bench.py --gpus N` started plainly (no WORLD_SIZE in the environment) starts its
+own N ranks through torch.distributed.run BEFORE anything touches the GPU and passes rank 0's line on; started by a
+launcher it takes RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment. The reference needs no launcher
+because its workers are threads of one process (SceneManager.h:392-404, :441-459); a rank per GPU is their counterpart.
+A WORLD_SIZE that differs from --gpus is an error, never a silent one-rank run.
 
 Prints ONE JSON line on rank 0.
 """
@@ -59,6 +63,7 @@ def parse():
     ap.add_argument("--share-of", type=int, default=1, metavar="N",
                     help="rehearsal on one GPU: render only rank 0's share of an N-rank run (no exchange); value = this share's rays/s")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--print-launch-plan", action="store_true", help="print the command a plain --gpus N run would start for its ranks, and exit (CPU test)")
     return ap.parse_args()
 
 
@@ -210,20 +215,61 @@ def adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, barrier):
             "rounds": log[:2] + log[-3:]}
 
 
+def launch_plan(argv, gpus, port):
+    """The command a plain `python3 bench.py --gpus N ...` runs instead of itself: N ranks of this file on this node
+    (what the reference's spawn_threads / assign_iterative_groups do with threads, SceneManager.h:392-404, :441-459)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher's environment: start the N ranks as a child job (nothing in this process has
+    touched the GPU or imported torch yet) and exit with its status. The children see WORLD_SIZE and take the other path."""
+    import subprocess
+    cmd = launch_plan(argv, args.gpus, free_port())
+    if args.print_launch_plan:
+        print(json.dumps({"launch_plan": cmd}), flush=True)
+        return 0
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if args.print_launch_plan:
+        print(json.dumps({"launch_plan": None}), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # both directions: a launcher with more ranks than --gpus, and --gpus N inside a one-rank environment
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a job of a different size")
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible and there is no CPU path")
     if args.one_device:
+        if args.backend == "nccl" and world > 1:
+            raise SystemExit("bench.py: --one-device puts every rank on cuda:0, which RCCL cannot do: use --backend gloo")
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} device(s) are visible "
+                         f"(--gpus {args.gpus} needs one GPU per rank; --one-device --backend gloo rehearses on one)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
@@ -273,21 +319,20 @@ def main():
     # (every rank's rows of the per-pixel error map, all-gathered, + the minimum sample count) and the framebuffer
     # all-gather (main + aux in one collective). Through the library's own srx_group (RCCL loaded by libsrx.so) when the
     # ranks sit on GPUs of their own; over torch.distributed otherwise (gloo rehearsals) or if the group cannot be made.
-    grp, exchange_path, NCx, err = None, "none (one rank)", None, None
+    grp, exchange_path, NCx, err, nranks_seen = None, "none (one rank)", None, None, 1
     if world > 1:
         NCx = engine.NoiseController(W, H, seed=args.seed, device=local_rank)
         err = torch.zeros(W * H, dtype=torch.float32, device="cuda")
-        exchange_path = "torch.distributed (" + args.backend + "), rows packed with torch index ops"
-        if args.backend == "nccl" and not args.one_device and os.environ.get("SRX_BENCH_EXCHANGE", "srx") == "srx":
-            try:
-                grp = tiles.Group.from_torch_dist()
-                exchange_path = "srx_group (C-ABI, RCCL)"
-            except Exception as e:                      # noqa: BLE001  (reported in the JSON line, not hidden)
-                exchange_path += f"; srx_group unavailable: {e}"
-        ok = torch.tensor([1 if grp is not None else 0], device="cuda")
-        dist.all_reduce(ok if args.backend == "nccl" else ok.cpu(), op=dist.ReduceOp.MIN)
-        if grp is not None and int(ok.item()) == 0:     # some rank has no group: nobody uses it
-            grp.close(); grp = None
+        if args.backend == "nccl":
+            # the C-ABI path or nothing: a failure to make the group fails the run (no measurement on another path)
+            grp = tiles.Group.from_torch_dist()
+            exchange_path = "srx_group (C-ABI, RCCL)"
+            nranks_seen = grp.nranks_seen()
+            if nranks_seen != world:
+                raise SystemExit(f"bench.py: srx_group reports {nranks_seen} ranks, the job has {world}")
+        else:
+            exchange_path = "torch.distributed (" + args.backend + "), rows packed with torch index ops (rehearsal, not RCCL)"
+            nranks_seen = dist.get_world_size()
 
     def exchange():
         if world <= 1:
@@ -407,6 +452,8 @@ def main():
                             f"monte_carlo_max {desc.monte_carlo_max} (not the headline workload)",
                 "parallelism": f"interleaved tile rows x{world}, scene replicated",
                 "exchange": exchange_path,
+                "nranks_seen": nranks_seen,
+                "launcher": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "none (one process)",
                 "rays_per_step": rays / args.steps,
                 "shadow_rays_per_step": agg["shadows_cast"] / args.steps,
                 "ray_capacity": args.ray_capacity,

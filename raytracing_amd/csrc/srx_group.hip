@@ -172,7 +172,19 @@ extern "C" void srx_group_destroy(srx_group* g) {
 }
 
 namespace {
+// A group belongs to the GPU that was current when it was made (its stream, its slots, its communicator): a collective
+// called with another device current would launch the pack kernels and the RCCL calls from the wrong context.
+int check_device(const srx_group* g, const char* who) {
+    int dev = -1;
+    SRX_HIP(hipGetDevice(&dev));
+    if (dev != g->device)
+        SRX_FAIL(std::string(who) + ": the group was made on device " + std::to_string(g->device) + " but device " + std::to_string(dev) +
+                 " is current (hipSetDevice to the group's GPU before the call)");
+    return 0;
+}
+
 int gather_rows(srx_group* g, float* const* frames, int n_frames, int fpp, int res_x, int res_y, int group_rows) {
+    if (check_device(g, "srx_group_gather")) return 1;
     if (check_rows("srx_group_gather", fpp, res_x, res_y, group_rows, g->rank, g->nranks)) return 1;
     const size_t per_frame = (size_t)most_rows(res_y, group_rows, g->nranks) * res_x * fpp;
     const size_t slot = per_frame * n_frames;
@@ -208,6 +220,7 @@ extern "C" int srx_group_allgather_rows(srx_group* g, float* d_frame, int32_t fl
 extern "C" int srx_group_allreduce(srx_group* g, double* d_sums, uint32_t n_sums, int32_t* d_mins, uint32_t n_mins) {
     if (!g) SRX_FAIL("srx_group_allreduce: null group");
     if ((n_sums && !d_sums) || (n_mins && !d_mins)) SRX_FAIL("srx_group_allreduce: null argument");
+    if (check_device(g, "srx_group_allreduce")) return 1;
     if (n_sums) SRX_RCCL(g_rccl.AllReduce(d_sums, d_sums, n_sums, RCCL_FLOAT64, RCCL_SUM, g->comm, g->stream));
     if (n_mins) SRX_RCCL(g_rccl.AllReduce(d_mins, d_mins, n_mins, RCCL_INT32, RCCL_MIN, g->comm, g->stream));
     SRX_HIP(hipStreamSynchronize(g->stream));

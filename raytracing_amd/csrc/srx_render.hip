@@ -264,6 +264,11 @@ int process_chain(srx_renderer* r, int gen, uint64_t begin, uint64_t n) {
     const GScene& g = r->scene->g;
     const int links = g.max_generations - gen + 1;
     GRay* const region[2] = {r->rays + r->top, r->rays + r->top + n};
+    // The shadow kernels of an earlier chain of this call (second stream, lowest priority) read their ray counts from the
+    // ring when their blocks START: the ring is cleared only after every one of them is over, on the device (the main
+    // stream waits for both queues' events; the host does not). Without this a block dispatched after the memset saw a
+    // count of 0 and dropped its shadow rays (tests/test_shade_gpu.py::test_chains_back_to_back).
+    if (join_shadows(r)) return 1;
     SRX_HIP(hipMemsetAsync(r->d_ring, 0, (size_t)links * sizeof(DeviceCounts), r->stream));
     const GRay* in = r->rays + begin;
     const uint32_t* n_ptr = nullptr;

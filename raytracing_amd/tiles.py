@@ -164,6 +164,15 @@ class Group:
             dist.broadcast_object_list(box, src=0)
         return cls(box[0], rank, world)
 
+    def nranks_seen(self) -> int:
+        """The number of ranks the library's communicator was made for (`srx_group_rank`), as the library reports it."""
+        C = self.C
+        r, n = C.c_int32(-1), C.c_int32(-1)
+        self._check(self.L.srx_group_rank(self.h, C.byref(r), C.byref(n)), "srx_group_rank")
+        if r.value != self.rank:
+            raise RuntimeError(f"srx_group_rank says rank {r.value}, this process is rank {self.rank}")
+        return int(n.value)
+
     def close(self):
         if self.h:
             self.L.srx_group_destroy(self.h)

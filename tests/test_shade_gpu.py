@@ -232,6 +232,40 @@ def test_shadow_stream_on_and_off_give_the_same_pass(loaded, monkeypatch):
     assert np.allclose(x1[:, :3], x0[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
 
 
+@pytest.mark.parametrize("mcm,cap", [(1, 1 << 12), (1, 1 << 11), (32, 1 << 15)])
+def test_chains_back_to_back(tables, monkeypatch, mcm, cap):
+    """Chain mode (generations of fan-out 1 enqueued back to back, counts read on the device, csrc/srx_render.hip
+    process_chain) against SRX_CHAIN=0 (a host round trip per generation) where SEVERAL chains run in one call: a small
+    ray_capacity splits a segment into batches, and with fan-out 32/8/2 the depth-first recursion starts a chain per
+    batch of generation 3. Scene with a sun: the shadow kernels of one chain's last links (second stream, lowest
+    priority) are still dispatching blocks when the next chain begins; clearing the count ring under them dropped their
+    shadow rays. Rays, shadow rays, every traversal counter and the image must equal the unchained run."""
+    import torch
+    from raytracing_amd import engine, scenes
+    desc = scenes.atrium(16384, res=(96, 54), subdiv=2, tex_size=64, monte_carlo_max=mcm)
+    PS = engine.package(desc, tables=tables)
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SRX_CHAIN", flag)
+        RE = engine.RayEngine(0)
+        RE.load_scene(PS)
+        acc = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+        cs = [RE.trace_pass(cam, (0, 0, w, h), p, 5, acc, None, ray_capacity=cap) for p in range(3)]
+        torch.cuda.synchronize()
+        out.append((acc.cpu().numpy(), cs))
+        RE.close()
+    (a1, c1), (a0, c0) = out
+    for ca, cb in zip(c1, c0):
+        for k in ("rays_processed", "shadows_cast", "nodes", "packets", "shadow_nodes", "shadow_packets", "hits"):
+            assert int(ca[k]) == int(cb[k]), k
+        assert int(ca["shadows_cast"]) > 0
+    assert int(c1[0]["trace_launches"]) > desc.max_generations + 1      # more launches than one chain has links: several chains per call
+    assert np.array_equal(a1[:, 3], a0[:, 3])
+    assert np.allclose(a1[:, :3], a0[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
+
+
 def test_converged_image_matches_reference_rng_estimator(tables):
     """Property test at image level: the GPU (keyed per-ray streams, throughput carried down the path, float atomics)
     and the oracle in REFERENCE mode (one sequential xoshiro stream, recursion multiplying on the way back,
