@@ -15,6 +15,7 @@
 #include <fstream>
 #include <memory>
 #include <thread>
+#include <sys/stat.h>
 #include "spatialray_adapter.hpp"
 
 using namespace spatialray;
@@ -40,6 +41,11 @@ int main(int argc, char** argv) {
         }
         const bool grouped = !id_file.empty();
         if (grouped && (nranks < 1 || rank < 0 || rank >= nranks)) throw std::runtime_error("bad --rank / --nranks");
+        // An id file left by an earlier job that died would make the other ranks join a dead communicator and hang in
+        // ncclCommInitRank: rank 0 removes it before anything else and again once every rank has joined, and the other
+        // ranks take no file older than 10 minutes before their own start (start the ranks together, rank 0 first or not).
+        const time_t started = time(nullptr);
+        if (grouped && rank == 0) std::remove(id_file.c_str());
         argc = n_pos;
         const int res_x = std::atoi(argv[2]), res_y = std::atoi(argv[3]), subdiv = std::atoi(argv[4]), spp = std::atoi(argv[5]);
         const uint64_t seed = std::strtoull(argv[6], nullptr, 10);
@@ -65,13 +71,16 @@ int main(int argc, char** argv) {
                 std::rename((id_file + ".tmp").c_str(), id_file.c_str());
             } else {
                 for (int tries = 0;; tries++) {
+                    struct stat sb;
+                    const bool fresh = stat(id_file.c_str(), &sb) == 0 && sb.st_mtime + 600 >= started;
                     std::ifstream f(id_file, std::ios::binary);
-                    if (f && f.read(id.data(), 128)) break;
+                    if (fresh && f && f.read(id.data(), 128)) break;
                     if (tries > 600) throw std::runtime_error("no communicator id appeared in " + id_file);
                     std::this_thread::sleep_for(std::chrono::milliseconds(100));
                 }
             }
             group.reset(new Group(id, rank, nranks));
+            if (rank == 0) std::remove(id_file.c_str());         // every rank has joined: the id has served
         }
 
         FrameBuffers frame(res_x, res_y);

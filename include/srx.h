@@ -169,6 +169,11 @@ int srx_cast_closest_device(srx_scene* scene, const float* d_org3, const float* 
  * (optional, device, zeroed by the caller) is added to, as in srx_cast_closest_device. */
 int srx_cast_closest_device_static(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, srx_hit* d_hits,
                                    uint64_t* d_counters2, void* stream);
+/* Diagnostic of the call above (no counterpart in the reference either): waits for `stream` and reports in *truncated
+ * whether a traversal wave of the last static call on the current GPU found no free overflow area and ended its rays
+ * early. That cannot happen with one call at a time; overlapping calls on one GPU (which the call above says race) can
+ * cause it, and a caller that cannot rule them out must check this before trusting d_hits. Allocates nothing. */
+int srx_static_scratch_status(void* stream, int32_t* truncated);
 /* replace `RayEngine::execute_lighting_cast(XYZ, Light*)` (Core.h:351-358) for sun lights:
  * lit[i] = 1 iff the closest hit along dir is farther than 9999 (Primitives.h:44-50). */
 int srx_cast_shadow(srx_scene* scene, const float* org3, const float* dir3, uint32_t n, uint8_t* lit);
@@ -333,6 +338,14 @@ int srx_trace_dealing(uint32_t n, int32_t k, uint32_t tail_blocks, uint32_t max_
 /* ... and which logical block each hardware block of a launch of nblk (a multiple of 8) blocks takes: XCD b % 8 works through
  * interleaved chunks of `chunk` logical blocks. logical[nblk]; a permutation of 0 .. nblk - 1. */
 int srx_trace_xcd_map(uint32_t nblk, uint32_t chunk, uint32_t* logical);
+
+/* The shading path's device math over arrays, for parity tests against the reference's own object code (no render path
+ * calls it): per element i, with a = a3[i], b = b3[i], c = c3[i], q = q4[i], out26[26 i ..] =
+ *   XYZ::reflect(a, b) [0..2] (XYZ.cpp:178-186), cross(a, b) [3..5] (:292), normalize(a) [6..8] (:237), dot(a, b) [9] (:279),
+ *   cdot(a, b) [10] (:282), Quat::applyRotation(a, q) [11..13] (:679-683), linear_mix(s, a, b) [14..16] (:397),
+ *   Matrix3x3::applyTBNMatrix(a, T = b, B = c, N = q.xyz) [17..19] (Matrix.h:62-64), VecLib::full_sin / full_cos / tan of a.x
+ *   [20..22] (VecLib.cpp:186-267), `s - a` with quirk Q4 [23..25] (XYZ.cpp:431-433). Host pointers. */
+int srx_math_probe(const float* a3, const float* b3, const float* c3, const float* q4, float s, uint32_t n, float* out26);
 
 /* ---- multi-GPU exchange: one process per GPU, scene replicated, tile rows dealt round-robin
  * (srx_trace_pass_interleaved), nothing exchanged on the sample path. What the reference's worker threads hand over in

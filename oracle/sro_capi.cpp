@@ -559,6 +559,14 @@ void sro_misc(const float* a3, const float* b3, float c, uint32_t n, float* fmin
         slope3[3 * i] = s.X; slope3[3 * i + 1] = s.Y; slope3[3 * i + 2] = s.Z;
     }
 }
+// Matrix3x3::applyTBNMatrix (Matrix.h:62-64) as restated in sro_math.h: pinned against the reference's header by tests
+void sro_apply_tbn(const float* p3, const float* t3, const float* b3, const float* n3, uint32_t n, float* out3) {
+    for (uint32_t i = 0; i < n; i++) {
+        XYZ r = applyTBNMatrix(XYZ(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), XYZ(t3[3 * i], t3[3 * i + 1], t3[3 * i + 2]),
+                               XYZ(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]), XYZ(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]));
+        out3[3 * i] = r.X; out3[3 * i + 1] = r.Y; out3[3 * i + 2] = r.Z;
+    }
+}
 void sro_apply_rotation(const float* p3, const float* q4, uint32_t n, float* out3) {
     for (uint32_t i = 0; i < n; i++) {
         Quat q; q.X = q4[4 * i]; q.Y = q4[4 * i + 1]; q.Z = q4[4 * i + 2]; q.W = q4[4 * i + 3];

@@ -67,6 +67,25 @@ def q_multiply(q2, q1):
         q1[3] * q2[3] - q1[0] * q2[0] - q1[1] * q2[1] - q1[2] * q2[2]], F)
 
 
+def collapse_transforms(ts):
+    """Transformation::collpase (Transformation.h:47-56) over a chain of ("move", xyz) / ("rot", quat) steps, each
+    stacked with Transformation::stack (:24-33): a move adds to the position, a rotation multiplies the quaternion and
+    rotates the position so far. Returns (position, rotation)."""
+    pos, rot = v3(0, 0, 0), np.array([0, 0, 0, 1], F)
+    for kind, val in ts:
+        if kind == "move":
+            pos = pos + val
+        else:
+            rot = q_multiply(rot, val)
+            pos = apply_rotation(pos, val)
+    return pos, rot
+
+
+def apply_transform(p, pos, rot):
+    """Transformation::apply (Transformation.h:35-42): rotate, then translate."""
+    return apply_rotation(p, rot) + pos
+
+
 def num(a, i):
     return float(a[i]) if i < len(a) and isinstance(a[i], (int, float)) else 0.0
 
@@ -368,18 +387,12 @@ def load(path):
         s = compile_scale(oi, v3(1, 1, 1))
         ts = []
         compile_transforms(oi, ts)
-        pos, rot = v3(0, 0, 0), np.array([0, 0, 0, 1], F)
-        for kind, val in ts:
-            if kind == "move":
-                pos = pos + val
-            else:
-                rot = q_multiply(rot, val)
-                pos = apply_rotation(pos, val)
+        pos, rot = collapse_transforms(ts)
         for p1, p2, p3, uv, n, mat in meshes[o["mesh"]]:
             ps = []
             for p in (p1, p2, p3):
                 q = (p - o["origin"]) * s
-                q = apply_rotation(q, rot) + pos
+                q = apply_transform(q, pos, rot)
                 ps.append(q + o["origin"])
             ns = [apply_rotation(x, rot) for x in n]
             out_tris.append((np.concatenate(ps), uv, np.concatenate(ns), mat))

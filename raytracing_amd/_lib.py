@@ -15,13 +15,13 @@ EXPORTS = [
     "srx_last_error", "srx_init",
     "srx_package_create", "srx_package_create_fast", "srx_package_get", "srx_package_get_order", "srx_package_destroy", "srx_build_tables",
     "srx_scene_create", "srx_scene_destroy", "srx_scene_stack_bound", "srx_scene_stack_spills",
-    "srx_cast_closest", "srx_cast_closest_device", "srx_cast_closest_device_static", "srx_cast_shadow", "srx_cast_shadow_device",
+    "srx_cast_closest", "srx_cast_closest_device", "srx_cast_closest_device_static", "srx_static_scratch_status", "srx_cast_shadow", "srx_cast_shadow_device",
     "srx_renderer_create", "srx_renderer_destroy", "srx_renderer_set_timing",
     "srx_trace_pass", "srx_trace_pass_interleaved", "srx_trace_passes_interleaved", "srx_trace_pass_adaptive", "srx_process_rays", "srx_camera_rays", "srx_camera_rays_xorgen", "srx_xorgen_stream",
     "srx_noise_create", "srx_noise_destroy", "srx_noise_set_option", "srx_noise_error_map", "srx_noise_analyze", "srx_noise_regions", "srx_noise_priorities",
     "srx_buffer_create", "srx_buffer_destroy", "srx_buffer_read", "srx_buffer_write", "srx_buffer_clear", "srx_post_process", "srx_write_raw", "srx_read_raw", "srx_write_png",
     "srx_gltf_load", "srx_gltf_destroy", "srx_gltf_get", "srx_image_decode", "srx_trace_dealing", "srx_trace_xcd_map",
-    "srx_group_unique_id", "srx_group_create", "srx_group_destroy", "srx_group_rank", "srx_group_gather_framebuffer",
+    "srx_math_probe", "srx_group_unique_id", "srx_group_create", "srx_group_destroy", "srx_group_rank", "srx_group_gather_framebuffer",
     "srx_group_allgather_rows", "srx_group_allreduce", "srx_rows_slot_floats", "srx_rows_pack", "srx_rows_unpack",
 ]
 

@@ -456,6 +456,23 @@ extern "C" int srx_cast_closest_device_static(srx_scene* scene, const float* d_o
     return 0;
 }
 
+// Did a wave of a srx_cast_closest_device_static call on the CURRENT device find no free overflow area (its rays then
+// ended early: hits or misses that are not the reference's)? Cannot happen while the calls on a GPU do not overlap (there
+// are more areas than wave slots); two overlapping calls share the areas and re-zero each other's control words, and this
+// flag is how a caller finds out. Waits for `stream`, reads one word (no allocation), returns 0 with *truncated set.
+extern "C" int srx_static_scratch_status(void* stream, int32_t* truncated) {
+    if (!truncated) SRX_FAIL("srx_static_scratch_status: null argument");
+    int device = -1;
+    SRX_HIP(hipGetDevice(&device));
+    StaticScratch* sp = nullptr;
+    if (static_scratch_for(device, &sp)) return 1;
+    SRX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    uint32_t flag = 0;
+    SRX_HIP(hipMemcpy(&flag, &sp->ctl[1], sizeof(flag), hipMemcpyDeviceToHost));
+    *truncated = flag ? 1 : 0;
+    return 0;
+}
+
 extern "C" int srx_cast_shadow_device(srx_scene* scene, const float* d_org3, const float* d_dir3, uint32_t n, uint8_t* d_lit, void* stream) {
     if (!scene) SRX_FAIL("srx_cast_shadow_device: null scene");
     TraceArgs a;

@@ -145,6 +145,47 @@ def test_transform_arithmetic_matches_reference_object_code():
         assert np.array_equal(sro_gltf.apply_rotation(v[i], a4[i]).view(np.uint32), r3[i].view(np.uint32))
 
 
+REF_MATRIX = os.path.join(os.path.dirname(REF), "libref_matrix.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MATRIX), reason="oracle/_ref not built (needs /root/reference; run __graft_entry__.build())")
+def test_collapsed_transforms_match_reference_header():
+    """Transformation::stack / collpase / apply (Transformation.h:24-57, compiled unmodified into oracle/_ref/
+    libref_matrix.so): chains of the loader's rotation + move steps, up to a child under two parents, collapsed and applied
+    to points (rotate, then translate) and to normals (rotation only) must equal the oracle loader's arithmetic bit for
+    bit. The product's loader equals the oracle's float for float (test_loader_matches_oracle), so this pins both."""
+    import ctypes as C
+    R = C.CDLL(REF_MATRIX)
+    rng = np.random.default_rng(23)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    F = np.float32
+    for case in range(60):
+        depth = 1 + case % 3                                     # the loader stacks a node's (rot, move), then its parents'
+        ts, kinds, vals = [], [], []
+        for _ in range(depth):
+            q = rng.normal(size=4).astype(F)
+            if case % 4:
+                q = (q / np.sqrt((q * q).sum())).astype(F)       # unit quaternions, and (every 4th case) raw ones
+            mv = (rng.normal(size=3) * (10.0 ** rng.integers(-3, 4))).astype(F)
+            ts += [("rot", q), ("move", mv)]
+            kinds += [1, 0]
+            vals += [q, np.append(mv, F(0))]
+        if case == 7:
+            ts, kinds, vals = [], [], []                          # an empty chain: identity
+        kinds_a = np.asarray(kinds, np.int32)
+        vals_a = np.ascontiguousarray(np.asarray(vals, F).reshape(-1, 4)) if vals else np.zeros((0, 4), F)
+        n = 256
+        pts = (rng.normal(size=(n, 3)) * (10.0 ** rng.integers(-2, 3))).astype(F)
+        nrm = rng.normal(size=(n, 3)).astype(F)
+        out_p, out_n = np.zeros((n, 3), F), np.zeros((n, 3), F)
+        R.ref_collapse_apply(p(kinds_a), p(vals_a), C.c_uint32(len(kinds)), p(pts), p(nrm), C.c_uint32(n), p(out_p), p(out_n))
+        pos, rot = sro_gltf.collapse_transforms(ts)
+        got_p = np.stack([sro_gltf.apply_transform(sro_gltf.v3(*x), pos, rot) for x in pts])
+        got_n = np.stack([sro_gltf.apply_rotation(sro_gltf.v3(*x), rot) for x in nrm])
+        assert np.array_equal(got_p.view(np.uint32), out_p.view(np.uint32)), case
+        assert np.array_equal(got_n.view(np.uint32), out_n.view(np.uint32)), case
+
+
 def test_malformed_files_fail_loudly(tmp_path):
     """A cycle in the node hierarchy, an accessor beyond the buffer, an index beyond the vertices, a truncated file."""
     import json, struct
