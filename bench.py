@@ -48,8 +48,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20241111)
-    ap.add_argument("--scene", default="atrium", choices=["atrium", "interior", "diffuse_box"],
-                    help="atrium = the headline workload (configs[1]); interior = configs[2] (C3), diffuse_box = configs[4] (C5)")
+    ap.add_argument("--scene", default="atrium", choices=["atrium", "interior", "diffuse_box", "instanced"],
+                    help="atrium = the headline workload (configs[1]); interior = configs[2] (C3), diffuse_box = configs[4] (C5), "
+                         "instanced = configs[3] (C4: --tris / 1000 instances of a 1 000-triangle mesh, flattened)")
+    ap.add_argument("--mcm", type=int, default=0, metavar="N", help="monte_carlo_max override (Scene.h:29): C5 is run with 1 (its default here) and 32")
     ap.add_argument("--adaptive", type=int, default=0, metavar="MIN_SAMPLES",
                     help="not the headline run: after the timed steps, run the adaptive-sampling loop (controller's minimum_samples = "
                          "MIN_SAMPLES, analysis every 4 visits) and report it under config.adaptive")
@@ -72,19 +74,23 @@ def parse():
 L2_GATHER_PEAK_GBS = 16800.0
 
 
-def pmc_profile(tris, res, scene="atrium"):
-    """Per-ray counter figures of the dominant kernel from the committed PMC profile (rocprofv3 --pmc needs runs of its
-    own, so they cannot be collected inside the timed run): profiles/r02_pmc_derived.json, made by tools/pmc_derive.py
-    from profiles/r02_pmc_raw.txt. None when the workload differs from the profiled one."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_derived.json")) as fh:
-            t = json.load(fh)
-        w = t["workload"]
-        if scene == "atrium" and w["tris"] == tris and w["res"] == res and w["max_generations"] == 8:
-            return t["k_trace<0>"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+def pmc_profile(n_tris, res, scene, max_generations, monte_carlo_max):
+    """Per-ray counter figures of the dominant kernel from the committed PMC profiles (rocprofv3 --pmc needs runs of its
+    own, so they cannot be collected inside the timed run): profiles/rNN_pmc_derived*.json, made by tools/pmc_derive.py
+    from the raw counter sums beside them, the newest round's file whose workload is this run's. (None, None) when no
+    committed profile covers the workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_derived*.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                t = json.load(fh)
+            w = t["workload"]
+            if (w.get("scene", "atrium") == scene and w["tris"] == n_tris and w["res"] == res and w["max_generations"] == max_generations
+                    and w.get("monte_carlo_max", 32) == monte_carlo_max):
+                return t["k_trace<0>"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def host_cpu():
@@ -284,8 +290,12 @@ def main():
         desc = scenes.atrium(args.tris, res=(W, H), subdiv=8, max_generations=8)
     elif args.scene == "interior":
         desc = scenes.interior(args.tris, res=(W, H), subdiv=8)
+    elif args.scene == "instanced":
+        desc = scenes.instanced(max(1, args.tris // 1000), 1000, res=(W, H), subdiv=8)
     else:
         desc = scenes.diffuse_box(args.tris, res=(W, H), subdiv=8)
+    if args.mcm > 0:
+        desc.monte_carlo_max = args.mcm
     cam = desc.camera
     t0 = time.perf_counter()
     PS = engine.package(desc, fast=args.fast_build)
@@ -387,7 +397,8 @@ def main():
         rays_per_launch = rays / launches
         # Memory-side traffic and cache-path figures per ray come from the committed PMC profile of this workload (kernels
         # alone on one stream); times are this run's HIP events. Every frac below is a fraction of a ceiling that can bind.
-        prof = pmc_profile(args.tris, args.res, args.scene)      # per-ray figures of the 1-GPU profile; a rank's share has the same rays per pixel
+        # per-ray figures of the 1-GPU profile of this workload; a rank's share has the same rays per pixel
+        prof, prof_path = pmc_profile(len(desc.tris), args.res, desc.name, desc.max_generations, desc.monte_carlo_max)
         traffic = prof["hbm_bytes_per_ray"] * rays_per_launch if prof else None
         hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
         l2_bytes = prof["l2_request_bytes_per_ray"] * rays_per_launch if prof else None
@@ -400,7 +411,8 @@ def main():
             "unit": "GB/s",
             "frac": hbm_gbs / HBM_PEAK_GBS if hbm_gbs else None,
             "traffic": traffic,
-            "traffic_source": "profiles/r02_pmc_derived.json <- r02_pmc_raw.txt (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per ray) x rays per launch",
+            "traffic_source": (f"{prof_path} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload, per ray) x rays per launch"
+                               if prof_path else None),
             "launches": int(launches),
             "avg_launch_ms": avg_ms,
             "algorithmic": {

@@ -446,3 +446,64 @@ def diffuse_box(n_clutter=50000, res=(1920, 1080), subdiv=4, max_generations=16,
     tris = np.concatenate(parts)
     cam = make_camera((0.0, -2.9, 0.0), res[0], res[1], subdiv, yfov_deg=70.0)
     return SceneDesc("diffuse_box", tris, mats, [], [], max_generations, monte_carlo_max, 0.25, cam)
+
+
+def instanced(n_instances=10_000, mesh_tris=1_000, res=(3840, 2160), subdiv=4, max_generations=8, monte_carlo_max=32, seed=13,
+              floor=True):
+    """C4 as SURVEY §8(d) words it: `n_instances` instances of ONE `mesh_tris`-triangle mesh on a jittered grid,
+    FLATTENED into world-space triangles (the reference has no instancing at trace time: `Object::fetchData` applies
+    every object's transform to its mesh's triangles, Primitives.h:423-434), n_instances x mesh_tris triangles (+ 8 192
+    of a displaced floor unless floor=False). Each instance has its own rotation about Z, scale and jittered position;
+    vertex normals are rotated only, as the reference does. The grid is centred on the origin (quirk Q1 applies to every
+    leaf), the floor is displaced per vertex (quirk Q3). One sun; 4 materials dealt per instance."""
+    rng = np.random.default_rng(seed)
+    # the mesh: a dented sphere of exactly mesh_tris triangles (2 x nseg x nrow), smooth normals
+    nrow = max(2, int(round(math.sqrt(mesh_tris / 2.0 / 1.25))))
+    nseg = max(3, mesh_tris // (2 * nrow))
+    base = sphere_mesh((0, 0, 0), 1.0, nseg, nrow, 0)
+    if len(base) < mesh_tris:                                            # top up with copies of the first triangles, shrunk inside
+        extra = base[: mesh_tris - len(base)].copy()
+        extra["p"] *= np.float32(0.5)
+        base = np.concatenate([base, extra])
+    base = base[:mesh_tris]
+    P0 = base["p"].reshape(-1, 3, 3).astype(np.float64)
+    r = np.linalg.norm(P0, axis=-1, keepdims=True)
+    dent = 1.0 + 0.12 * np.sin(5.0 * P0[..., 0:1]) * np.cos(4.0 * P0[..., 2:3])
+    P0 = P0 * dent
+    N0 = base["n"].reshape(-1, 3, 3).astype(np.float64)
+    side = int(math.ceil(math.sqrt(n_instances)))
+    pitch = 1.0
+    half = 0.5 * side * pitch
+    mats = np.stack([
+        material((0.75, 0.75, 0.72), roughness=0.8),
+        material((0.8, 0.45, 0.2), roughness=0.4),
+        material((0.3, 0.5, 0.8), roughness=0.6),
+        material((0.85, 0.85, 0.9), roughness=0.15, metallic=1.0),
+        material((0.55, 0.6, 0.5), roughness=0.9),                       # 4 floor
+    ])
+    tris = np.zeros(n_instances * mesh_tris + (8192 if floor else 0), TRI_DTYPE)
+    chunk = 256
+    for i0 in range(0, n_instances, chunk):
+        i1 = min(n_instances, i0 + chunk)
+        k = np.arange(i0, i1)
+        gx, gy = k % side, k // side
+        jit = rng.uniform(-0.22, 0.22, size=(len(k), 2))
+        sc = rng.uniform(0.22, 0.32, size=len(k))
+        ang = rng.uniform(0, 2 * np.pi, size=len(k))
+        cs, sn = np.cos(ang), np.sin(ang)
+        R = np.zeros((len(k), 3, 3)); R[:, 0, 0] = cs; R[:, 0, 1] = -sn; R[:, 1, 0] = sn; R[:, 1, 1] = cs; R[:, 2, 2] = 1
+        T = np.stack([(gx + 0.5) * pitch - half + jit[:, 0], (gy + 0.5) * pitch - half + jit[:, 1], sc * 1.05 + 0.01], -1)
+        P = np.einsum("iab,tvb->itva", R, P0) * sc[:, None, None, None] + T[:, None, None, :]
+        N = np.einsum("iab,tvb->itva", R, N0)
+        blk = tris[i0 * mesh_tris:i1 * mesh_tris]
+        blk["p"] = P.reshape(-1, 9).astype(np.float32)
+        blk["n"] = N.reshape(-1, 9).astype(np.float32)
+        blk["uv"] = np.tile(base["uv"], (len(k), 1))
+        blk["material"] = np.repeat(k % 4, mesh_tris)
+        blk["flags"] = 1
+    if floor:
+        tris[n_instances * mesh_tris:] = grid_mesh((-half - 2, -half - 2, 0.0), (2 * half + 4, 0, 0), (0, 2 * half + 4, 0), 64, 64, 4, rng, 2e-3)
+    sun_dir = np.array((0.35, 0.2, 0.9)); sun_dir /= np.linalg.norm(sun_dir)
+    tilt = -0.52
+    cam = make_camera((0.3, -half - 1.0, 6.0), res[0], res[1], subdiv, yfov_deg=50.0, rotation=(math.sin(tilt / 2), 0.0, 0.0, math.cos(tilt / 2)))
+    return SceneDesc("instanced", tris, mats, [], [(tuple(sun_dir), (2.5, 2.4, 2.2))], max_generations, monte_carlo_max, 0.25, cam)

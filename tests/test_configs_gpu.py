@@ -1,7 +1,8 @@
 """The two BASELINE.json configurations round 1 left without a GPU test.
 
-C4 (configs[3]): 10 M triangles at 3840x2160, 8 GPUs tile-sharded. Here: the 10 M-triangle atrium, package equality of
-the product's threaded builder and the oracle, every 97th 4K primary and its secondary ray against the oracle at 0 ulp
+C4 (configs[3]): 10 M triangles at 3840x2160, 8 GPUs tile-sharded. Here, as SURVEY 8(d) words it: 10 000 instances of a
+1 000-triangle mesh on a jittered grid, flattened (scenes.instanced; the reference has no instancing at trace time,
+Primitives.h:423-434), package equality of the product's threaded builder and the oracle, every 97th 4K primary and its secondary ray against the oracle at 0 ulp
 with equal traversal counters, and one rank's 1/8 interleaved share of the 4K frame (two passes in one call) through
 size-independent properties plus an oracle crop.
 
@@ -23,8 +24,8 @@ def test_c4_ten_million_triangles_at_4k(tables):
     import torch
     from oracle import sro
     from raytracing_amd import engine, scenes, tiles
-    desc = scenes.atrium(10_000_000, res=(3840, 2160), subdiv=4, max_generations=8, tex_size=64)
-    assert len(desc.tris) == 10_000_000
+    desc = scenes.instanced(10_000, 1_000, res=(3840, 2160), subdiv=4, max_generations=8)
+    assert len(desc.tris) == 10_000 * 1_000 + 8192                 # the instances + the displaced floor
     PS = engine.package(desc, tables=tables)
     S = sro.OracleScene(desc, tables=tables)
     on, op, ot = S.packaged()
@@ -32,7 +33,7 @@ def test_c4_ten_million_triangles_at_4k(tables):
     del on, op, ot
     RE = engine.RayEngine(0)
     RE.load_scene(PS)
-    assert RE.stack_bound() > 52                                   # deeper than the LDS budget: the overflow form of the kernel runs
+    assert RE.stack_bound() >= 40                                  # deep enough for the overflow form of the kernel (SRX_SPILL_MIN_BOUND)
     cam = desc.camera
     w, h = int(cam["res_x"]), int(cam["res_y"])
     # ---- every 97th primary of the 4K frame and a secondary ray from its hit point

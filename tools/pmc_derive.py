@@ -20,8 +20,12 @@ bench = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
 out = {}
 if bench:
     import re as _re
-    m = _re.search(r"(\d+) tris, (\d+x\d+)", bench["config"]["workload"])
-    out["workload"] = {"tris": int(m.group(1)), "res": m.group(2), "max_generations": 8}
+    wl = bench["config"]["workload"]
+    m = _re.search(r"(\d+) tris, (\d+x\d+)", wl)
+    mg = _re.search(r"max_generations (\d+)", wl); mc = _re.search(r"monte_carlo_max (\d+)", wl)
+    scene = "atrium" if wl.startswith("procedural Sponza-class atrium") else wl.split(",")[0].strip()
+    out["workload"] = {"scene": scene, "tris": int(m.group(1)), "res": m.group(2), "max_generations": int(mg.group(1)) if mg else 8,
+                       "monte_carlo_max": int(mc.group(1)) if mc else 32}
     out["rays_per_pass"] = bench["config"]["rays_per_step"]
     out["shadow_rays_per_pass"] = bench["config"]["shadow_rays_per_step"]
 for k in ("k_trace<0>", "k_trace<2>", "k_shade"):

@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 run() { # name, counters...
   n=$1; shift
-  timeout -s KILL 170 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fast-tree > $OUT/$n.log 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fast-tree $BENCH_ARGS > $OUT/$n.log 2>&1
   echo "pass $n exit $?"
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU && \
