@@ -441,6 +441,8 @@ def main():
             "fetched_bytes_per_ray": (256 * agg["nodes"] + 384 * agg["packets"]) / max(1.0, rays) + 24 + 20,
             "node_tests_per_ray": agg["nodes"] / max(1.0, rays),
             "packet_tests_per_ray": agg["packets"] / max(1.0, rays),
+            "shadow_node_tests_per_shadow_ray": agg["shadow_nodes"] / max(1.0, agg["shadows_cast"]),
+            "shadow_packet_tests_per_shadow_ray": agg["shadow_packets"] / max(1.0, agg["shadows_cast"]),
             "kernel_ms": {"trace": trace_ms, "shadow": shadow_ms, "shade": shade_ms, "wall": dt * 1e3},
         }
         out = {

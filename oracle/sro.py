@@ -134,6 +134,15 @@ class OracleScene:
         self._chk(self.L.sro_cast_closest(self.h, _p(org), _p(dirs), C.c_uint32(n), _p(out), _p(adv), _p(ctr)))
         return (out, ctr, adv) if want_advanced else (out, ctr)
 
+    def filter_margins(self, org, dirs):
+        """(largest |ray point - triangle point| / |o - p1|, largest distance outside the leaf's tight box / D, lanes) over
+        every lane the reference's triangle test passes in a leaf whose guard condition holds for the ray (sro_trace.h)."""
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.zeros(3, np.float64)
+        self._chk(self.L.sro_filter_margins(self.h, _p(org), _p(dirs), C.c_uint32(len(org)), _p(out)))
+        return float(out[0]), float(out[1]), int(out[2])
+
     def cast_shadow(self, org, dirs):
         org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
         dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)

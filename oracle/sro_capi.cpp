@@ -202,6 +202,24 @@ int sro_cast_closest(void* hv, const float* org3, const float* dir3, uint32_t n,
     return 0;
 }
 
+// The leaf filter's observed margins over a ray set (TraceCounters::max_r_over_T, max_outside_over_D, margin_lanes): scalar walk.
+int sro_filter_margins(void* hv, const float* org3, const float* dir3, uint32_t n, double* out3) {
+    Handle* h = (Handle*)hv;
+    TraceCounters c;
+    const bool simd = h->scene.geo.simd;
+    h->scene.geo.simd = false;
+    try {
+        for (uint32_t i = 0; i < n; i++) {
+            XYZ o(org3[3 * i], org3[3 * i + 1], org3[3 * i + 2]);
+            XYZ d(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]);
+            (void)execute_ray_cast(h->scene.geo, o, d, &c);
+        }
+    } catch (const std::exception& e) { h->scene.geo.simd = simd; g_err = e.what(); return 1; }
+    h->scene.geo.simd = simd;
+    out3[0] = c.max_r_over_T; out3[1] = c.max_outside_over_D; out3[2] = (double)c.margin_lanes;
+    return 0;
+}
+
 // Shadow cast toward a sun direction: lit iff the closest hit is farther than 9999 (Primitives.h:44-50).
 int sro_cast_shadow(void* hv, const float* org3, const float* dir3, uint32_t n, uint8_t* lit) {
     Handle* h = (Handle*)hv;

@@ -27,7 +27,29 @@ struct TraceCounters {
     uint64_t unhittable_accepts = 0;   // closest-hit updates (Core.h:233) taken in such a leaf: must stay 0 for the filter to be exact
     uint64_t packets_guarded = 0;      // tests in leaves the box test alone would skip but the normal-cone guard keeps
     uint64_t unhittable_passes = 0;    // lanes with u, v in range and t > 0 in such a leaf, whether nearer than the best hit or not
+    // How close the filter's soundness bound comes to being used, over every lane the reference's
+    // test PASSES (u, v in range, t > 0) in a leaf for which guard condition (2) holds for the ray, in double from the
+    // fp32 t, u, v: the distance between the triangle's point p1 + u e1 + v e2 and the ray's point o + t d, relative to
+    // |o - p1| (the argument bounds it by 1.6e-4), and how far outside the leaf's tight box the ray's point lies
+    // (Chebyshev), relative to D = the largest coordinate distance from the origin to the box (condition (1) pads by 5e-4 D).
+    double max_r_over_T = 0.0, max_outside_over_D = 0.0;
+    uint64_t margin_lanes = 0;
 };
+
+// Guard condition (2) of the leaf filter on its own: the ray is one the filter may act on at all, and it keeps clear of
+// the planes of all the leaf's triangles by the leaf's cone word (same arithmetic as leaf_filter below).
+static inline bool leaf_guard_holds(uint32_t cone, const XYZ& d, const XYZ& fused, const XYZ& inv) {
+    auto finite = [](float x) { return (bitcast<uint32_t>(x) & 0x7f800000u) != 0x7f800000u; };
+    if (!(finite(fused.X) && finite(fused.Y) && finite(fused.Z) && finite(inv.X) && finite(inv.Y) && finite(inv.Z))) return false;
+    const float dd = std::fmaf(d.Z, d.Z, std::fmaf(d.Y, d.Y, d.X * d.X));
+    if (!(dd >= 1e-12f && dd <= 1e12f)) return false;
+    const float dmin = std::min(std::min(std::fabs(d.X), std::fabs(d.Y)), std::fabs(d.Z));
+    if (!(dmin * dmin >= 1e-30f * dd)) return false;
+    const float sc = 127.0f / std::sqrt(dd);
+    const int qx = (int)std::nearbyint(d.X * sc), qy = (int)std::nearbyint(d.Y * sc), qz = (int)std::nearbyint(d.Z * sc);
+    const int s = (int)(int8_t)(cone & 255u) * qx + (int)(int8_t)((cone >> 8) & 255u) * qy + (int)(int8_t)((cone >> 16) & 255u) * qz;
+    return std::abs(s) >= (int)(cone >> 24) * 127;
+}
 
 // the product's leaf filter (node_test in raytracing_amd/csrc/srx_trace.hip), same arithmetic: a leaf is skipped when
 //  (1) the ray's slab interval against the stored (tight) box, widened by pt at both ends, is empty or behind the ray;
@@ -180,6 +202,9 @@ static inline void iterativeBVH_AVX(const PackagedGeometry& data, CastResults& r
                 verdict = leaf_filter(&data.filter_boxes[(size_t)slot_of[stack_index] * 6], data.filter_cones[slot_of[stack_index]], position, slope,
                                       fused, inv, data.filter_pad, PackagedGeometry::FILTER_PAD_REL, PackagedGeometry::FILTER_PAD_ABS);
             const bool unhittable = verdict == 0;
+            const bool measure = ctr && data.filter_enabled && !data.filter_boxes.empty() && slot_of[stack_index] >= 0 &&
+                                 leaf_guard_holds(data.filter_cones[slot_of[stack_index]], slope, fused, inv);
+            const float* mbox = measure ? &data.filter_boxes[(size_t)slot_of[stack_index] * 6] : nullptr;
             if (unhittable) ctr->packets_unhittable += (uint64_t)self_triangles;
             if (verdict == 2) ctr->packets_guarded += (uint64_t)self_triangles;
             stack_index--;
@@ -188,6 +213,22 @@ static inline void iterativeBVH_AVX(const PackagedGeometry& data, CastResults& r
                 float t[8], u[8], v[8];
                 packet_intersection(P, position, slope, t, u, v);
                 if (ctr) ctr->packets++;
+                for (int l = 0; l < 8 && measure; l++) {
+                    if (!(t[l] > 0)) continue;
+                    const double o3[3] = {position.X, position.Y, position.Z}, d3[3] = {slope.X, slope.Y, slope.Z};
+                    const double p1[3] = {P.p1X[l], P.p1Y[l], P.p1Z[l]}, e1[3] = {P.p1p2X[l], P.p1p2Y[l], P.p1p2Z[l]}, e2[3] = {P.p1p3X[l], P.p1p3Y[l], P.p1p3Z[l]};
+                    double r2 = 0, T2 = 0, outside = 0, D = 0;
+                    for (int ax = 0; ax < 3; ax++) {
+                        const double q = o3[ax] + (double)t[l] * d3[ax], tri = p1[ax] + (double)u[l] * e1[ax] + (double)v[l] * e2[ax];
+                        r2 += (q - tri) * (q - tri);
+                        T2 += (o3[ax] - p1[ax]) * (o3[ax] - p1[ax]);
+                        outside = std::max(outside, std::max((double)mbox[ax] - q, q - (double)mbox[3 + ax]));
+                        D = std::max(D, std::max(std::fabs((double)mbox[ax] - o3[ax]), std::fabs((double)mbox[3 + ax] - o3[ax])));
+                    }
+                    if (T2 > 0) ctr->max_r_over_T = std::max(ctr->max_r_over_T, std::sqrt(r2 / T2));
+                    if (D > 0) ctr->max_outside_over_D = std::max(ctr->max_outside_over_D, outside / D);
+                    ctr->margin_lanes++;
+                }
                 for (int l = 0; l < 8; l++) {           // Core.h:231-239
                     if (unhittable && t[l] > 0) { ctr->unhittable_passes++; if (t[l] < res.distance) ctr->unhittable_accepts++; }
                     if (t[l] > 0 && t[l] < res.distance) {

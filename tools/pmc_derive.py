@@ -31,6 +31,8 @@ if bench:
 for k in ("k_trace<0>", "k_trace<2>", "k_shade"):
     g = lambda c: tot[(k, c)]
     t = ms[k]; cyc = t * 1e-3 * 2.4e9
+    if t <= 0:                      # the workload never launches this kernel (no sun: no shadow kernel)
+        continue
     d = {"ms_per_pass": t, "launches": disp[(k, "SQ_WAVES")], "waves": g("SQ_WAVES"), "valu": g("SQ_INSTS_VALU"), "salu": g("SQ_INSTS_SALU"),
          "vmem_rd": g("SQ_INSTS_VMEM_RD"), "lds": g("SQ_INSTS_LDS"),
          "valu_busy": g("SQ_INSTS_VALU") / 1024 * 2 / cyc, "waves_per_simd": g("SQ_WAVE_CYCLES") * 4 / (cyc * 1024),
