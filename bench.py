@@ -186,28 +186,55 @@ def fast_tree_leg(args, RE, desc, cam, rect, share, accum, aux, B, barrier):
             "stack_depth": RE.stack_bound()}
 
 
-def adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, barrier):
+def adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, rank, grp, barrier):
     """SceneManager's mode-1 loop (SceneManager.h:970-993) on the GPU: visits of every 4x4 block with the
-    controller's priorities, analyze_noise + balance_threads every 4 visits (the reference: every 2 s)."""
+    controller's priorities, analyze_noise + balance_threads every 4 visits (the reference: every 2 s). With several
+    ranks the second half of balance_threads (:693-773) runs too: after every analysis the tile rows are re-dealt by
+    their burden (tiles.Deal, the same deal on every rank from the same priorities; the framebuffers are gathered under
+    the old deal first, because a rank that takes rows over continues their running means)."""
     import torch
+    import torch.distributed as dist
     from raytracing_amd import engine, tiles
     NC = engine.NoiseController(W, H, seed=args.seed, minimum_samples=args.adaptive)
     err = torch.zeros(W * H, dtype=torch.float32, device="cuda")
     prio = torch.ones(NC.n_blocks, dtype=torch.float32, device="cuda")
+    deal = tiles.Deal(W, H, world) if world > 1 and args.share_of <= 1 else None
     visit = args.warmup + args.steps
-    log, analyses_ms, visits_ms, rays = [], 0.0, 0.0, 0
+    log, analyses_ms, visits_ms, rays, moved_total = [], 0.0, 0.0, 0, 0
     while visit < args.warmup + args.steps + 4 * 12 + args.adaptive:
         barrier()
         t0 = time.perf_counter()
         for _ in range(4):
-            c = RE.trace_visit(cam, rect, visit, args.seed, accum, aux, block_priority=prio, ray_capacity=args.ray_capacity, interleave=share)
+            c = RE.trace_visit(cam, rect, visit, args.seed, accum, aux, block_priority=prio, ray_capacity=args.ray_capacity,
+                               interleave=share, deal=deal, part=rank)
             rays += c["rays_processed"]
             visit += 1
         barrier()
         t1 = time.perf_counter()
-        seen = tiles.allreduce_error_map(err, NC.error_map(accum, aux, err, interleave=share), H, W)
+        if deal is None:
+            seen = tiles.allreduce_error_map(err, NC.error_map(accum, aux, err, interleave=share), H, W)
+        else:
+            seen = NC.error_map(accum, aux, err, deal=deal, part=rank)
+            if grp is not None:
+                grp.allgather_rows_dealt(deal, err, 1)
+                mn = torch.tensor([int(seen)], dtype=torch.int32, device="cuda")
+                grp.allreduce(None, mn)
+                seen = int(mn.item())
+            else:
+                tiles.gather_framebuffer_dealt(err.view(H * W, 1), deal)
+                mn = torch.tensor([int(seen)], dtype=torch.int64)
+                dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+                seen = int(mn.item())
         NC.analyze_noise(err, seen)
-        NC.balance(seen, prio)
+        updated = NC.balance(seen, prio)
+        moved = 0
+        if deal is not None and updated:
+            if grp is not None:
+                grp.gather_framebuffer_dealt(deal, accum, aux)
+            else:
+                tiles.gather_framebuffer_dealt([accum, aux], deal)
+            moved = deal.rebalance(prio)
+            moved_total += moved
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         visits_ms += (t1 - t0) * 1e3
@@ -215,10 +242,14 @@ def adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, barrier):
         R = NC.regions()
         lum = tiles.luminance(accum[:, :3])
         log.append({"negative_luminance_pixels": int((lum < 0).sum()), "nan_error_pixels": int(torch.isnan(err).sum()),"visit": visit, "min_samples": seen, "regions": int(len(R)), "active_regions": int(R["active"].sum()),
-                    "mean_priority": float(prio.mean()), "visits_ms": (t1 - t0) * 1e3, "analysis_ms": (t2 - t1) * 1e3})
+                    "mean_priority": float(prio.mean()), "visits_ms": (t1 - t0) * 1e3, "analysis_ms": (t2 - t1) * 1e3, "tile_rows_moved": moved})
     NC.close()
-    return {"minimum_samples": args.adaptive, "visits_ms": visits_ms, "analyses_ms": analyses_ms, "rays_this_rank": rays,
-            "rounds": log[:2] + log[-3:]}
+    out = {"minimum_samples": args.adaptive, "visits_ms": visits_ms, "analyses_ms": analyses_ms, "rays_this_rank": rays,
+           "rounds": log[:2] + log[-3:]}
+    if deal is not None:
+        _, _, burdens = deal.tables()
+        out["deal"] = {"tile_rows_moved": moved_total, "burdens": [float(b) for b in burdens], "rows_of_this_rank": int(len(deal.rows_of(rank)))}
+    return out
 
 
 def launch_plan(argv, gpus, port):
@@ -370,7 +401,7 @@ def main():
 
     adaptive = None
     if args.adaptive > 0:
-        adaptive = adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, barrier)
+        adaptive = adaptive_loop(args, RE, cam, rect, share, accum, aux, W, H, world, rank, grp, barrier)
 
     keys = ["rays_processed", "shadows_cast", "nodes", "packets", "shadow_nodes", "shadow_packets", "hits",
             "trace_launches", "shadow_launches", "shade_launches"]

@@ -339,6 +339,32 @@ int srx_trace_dealing(uint32_t n, int32_t k, uint32_t tail_blocks, uint32_t max_
  * interleaved chunks of `chunk` logical blocks. logical[nblk]; a permutation of 0 .. nblk - 1. */
 int srx_trace_xcd_map(uint32_t nblk, uint32_t chunk, uint32_t* logical);
 
+/* ---- noise-weighted dealing of the frame's row groups to the ranks: replaces the second half of
+ * SceneManager::balance_threads (SceneManager.h:693-773), which after every analysis moves 4x4 blocks from the most
+ * burdened render thread's list to the least burdened one's until their burdens (sums of block priorities) are within
+ * 5 %. Here the unit is a group of group_rows pixel rows (a multiple of 4) and a part is a rank. A deal starts as the
+ * round-robin of srx_trace_pass_interleaved (assign_iterative_groups, :441-459). srx_deal_rebalance is a function of the
+ * block priorities alone (HOST array as srx_noise_priorities wrote them, copied back), which every rank holds
+ * identically after the error-map exchange: every rank arrives at the same deal, no collective. A rank that takes over
+ * rows needs their accumulated pixels: gather the framebuffers under the OLD deal before rebalancing. Host functions;
+ * no GPU needed for create / rebalance / get. */
+typedef struct srx_deal srx_deal;
+int srx_deal_create(int32_t res_x, int32_t res_y, int32_t group_rows, int32_t nparts, srx_deal** out);
+void srx_deal_destroy(srx_deal* d);
+int srx_deal_rebalance(srx_deal* d, const float* block_priority, uint32_t n_blocks, int32_t* groups_moved);
+/* owner[g] = the part group g belongs to, slot[g] = its index in that part's list (a part renders, packs and unpacks its
+ * groups in list order); *n_groups = ceil(res_y / group_rows); burdens[nparts] = each part's burden at the last rebalance. */
+int srx_deal_get(const srx_deal* d, int32_t* owner, int32_t* slot, uint32_t capacity, uint32_t* n_groups, float* burdens);
+/* the dealt forms of srx_trace_pass_adaptive (whole frame), srx_noise_error_map, the gathers and the row packing */
+int srx_trace_pass_adaptive_dealt(srx_renderer* r, const srx_camera* camera, srx_deal* deal, int32_t part, uint32_t visit_index, uint64_t seed,
+                                  const float* d_block_priority, float* d_accum4, float* d_aux4, srx_counters* counters);
+int srx_noise_error_map_dealt(srx_noise* c, const float* d_accum4, const float* d_aux4, srx_deal* deal, int32_t part, float* d_err,
+                              int32_t* min_samples);
+uint64_t srx_deal_slot_floats(const srx_deal* d, int32_t floats_per_pixel);
+int srx_rows_pack_dealt(srx_deal* d, const float* d_frame, int32_t floats_per_pixel, int32_t part, float* d_slot, void* stream);
+int srx_rows_unpack_dealt(srx_deal* d, const float* d_slots, uint64_t slot_stride_floats, uint64_t buffer_offset_floats, int32_t floats_per_pixel,
+                          int32_t skip_part, float* d_frame, void* stream);
+
 /* The shading path's device math over arrays, for parity tests against the reference's own object code (no render path
  * calls it): per element i, with a = a3[i], b = b3[i], c = c3[i], q = q4[i], out26[26 i ..] =
  *   XYZ::reflect(a, b) [0..2] (XYZ.cpp:178-186), cross(a, b) [3..5] (:292), normalize(a) [6..8] (:237), dot(a, b) [9] (:279),
@@ -369,6 +395,9 @@ int srx_group_gather_framebuffer(srx_group* g, float* d_accum4, float* d_aux4, i
  * every rank holds the complete map and srx_noise_analyze gives the same regions on every rank as on one GPU. */
 int srx_group_allgather_rows(srx_group* g, float* d_frame, int32_t floats_per_pixel, int32_t res_x, int32_t res_y, int32_t group_rows);
 /* In-place all-reduce over the ranks: d_sums[n_sums] doubles are summed, d_mins[n_mins] int32 take the minimum (device). */
+/* the two gathers under a deal (nparts of the deal = ranks of the group, part = rank) */
+int srx_group_gather_framebuffer_dealt(srx_group* g, srx_deal* deal, float* d_accum4, float* d_aux4);
+int srx_group_allgather_rows_dealt(srx_group* g, srx_deal* deal, float* d_frame, int32_t floats_per_pixel);
 int srx_group_allreduce(srx_group* g, double* d_sums, uint32_t n_sums, int32_t* d_mins, uint32_t n_mins);
 /* The row packing on its own, for a host that brings its own transport: a part's rows of a frame packed into a slot of
  * srx_rows_slot_floats() floats per frame (the size of the largest share, so slots are equal), and all parts' slots

@@ -21,7 +21,7 @@ EXPORTS = [
     "srx_noise_create", "srx_noise_destroy", "srx_noise_set_option", "srx_noise_error_map", "srx_noise_analyze", "srx_noise_regions", "srx_noise_priorities",
     "srx_buffer_create", "srx_buffer_destroy", "srx_buffer_read", "srx_buffer_write", "srx_buffer_clear", "srx_post_process", "srx_write_raw", "srx_read_raw", "srx_write_png",
     "srx_gltf_load", "srx_gltf_destroy", "srx_gltf_get", "srx_image_decode", "srx_trace_dealing", "srx_trace_xcd_map",
-    "srx_math_probe", "srx_group_unique_id", "srx_group_create", "srx_group_destroy", "srx_group_rank", "srx_group_gather_framebuffer",
+    "srx_math_probe", "srx_deal_create", "srx_deal_destroy", "srx_deal_rebalance", "srx_deal_get", "srx_trace_pass_adaptive_dealt", "srx_noise_error_map_dealt", "srx_deal_slot_floats", "srx_rows_pack_dealt", "srx_rows_unpack_dealt", "srx_group_gather_framebuffer_dealt", "srx_group_allgather_rows_dealt", "srx_group_unique_id", "srx_group_create", "srx_group_destroy", "srx_group_rank", "srx_group_gather_framebuffer",
     "srx_group_allgather_rows", "srx_group_allreduce", "srx_rows_slot_floats", "srx_rows_pack", "srx_rows_unpack",
 ]
 
@@ -78,6 +78,7 @@ def lib():
         L.srx_last_error.restype = C.c_char_p
         L.srx_scene_stack_spills.restype = C.c_int64
         L.srx_rows_slot_floats.restype = C.c_uint64
+        L.srx_deal_slot_floats.restype = C.c_uint64
         _LIB = L
     return _LIB
 

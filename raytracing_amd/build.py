@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["srx_trace.hip", "srx_shade.hip", "srx_scene.hip", "srx_render.hip", "srx_noise.hip", "srx_post.hip", "srx_group.hip", "srx_probe.hip", "srx_packager.cpp", "srx_gltf.cpp"]
+SOURCES = ["srx_trace.hip", "srx_shade.hip", "srx_scene.hip", "srx_render.hip", "srx_noise.hip", "srx_post.hip", "srx_group.hip", "srx_probe.hip", "srx_deal.hip", "srx_packager.cpp", "srx_gltf.cpp"]
 OUT = os.path.join(HERE, "libsrx.so")
 # -ffp-contract=off: FMAs only where the kernels say __fmaf_rn (bit parity with the CPU path);
 # denormals are kept (no -fgpu-flush-denormals-to-zero); correctly rounded fp32 divide/sqrt (HIP default).

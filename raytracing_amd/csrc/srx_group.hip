@@ -217,6 +217,41 @@ extern "C" int srx_group_allgather_rows(srx_group* g, float* d_frame, int32_t fl
     return gather_rows(g, frames, 1, floats_per_pixel, res_x, res_y, group_rows);
 }
 
+namespace {
+int gather_rows_dealt(srx_group* g, srx_deal* deal, float* const* frames, int n_frames, int fpp) {
+    if (check_device(g, "srx_group_gather (dealt)")) return 1;
+    if (deal->nparts != g->nranks) SRX_FAIL("srx_group_gather (dealt): the deal has " + std::to_string(deal->nparts) + " parts, the group " + std::to_string(g->nranks) + " ranks");
+    if (fpp <= 0 || fpp > 16) SRX_FAIL("srx_group_gather (dealt): bad floats per pixel");
+    const size_t per_frame = (size_t)srx_deal_most_rows(deal) * deal->res_x * fpp;
+    const size_t slot = per_frame * n_frames;
+    if (g->slots_floats < slot * g->nranks) {
+        if (g->d_slots) { SRX_HIP(hipStreamSynchronize(g->stream)); SRX_HIP(hipFree(g->d_slots)); g->d_slots = nullptr; g->slots_floats = 0; }
+        SRX_HIP(hipMalloc((void**)&g->d_slots, slot * g->nranks * sizeof(float)));
+        g->slots_floats = slot * g->nranks;
+    }
+    float* mine = g->d_slots + (size_t)g->rank * slot;
+    for (int f = 0; f < n_frames; f++)
+        if (srx_rows_pack_dealt(deal, frames[f], fpp, g->rank, mine + (size_t)f * per_frame, g->stream)) return 1;
+    SRX_RCCL(g_rccl.AllGather(mine, g->d_slots, slot, RCCL_FLOAT32, g->comm, g->stream));
+    for (int f = 0; f < n_frames; f++)
+        if (srx_rows_unpack_dealt(deal, g->d_slots, slot, (size_t)f * per_frame, fpp, g->rank, frames[f], g->stream)) return 1;
+    SRX_HIP(hipStreamSynchronize(g->stream));
+    return 0;
+}
+}  // namespace
+
+extern "C" int srx_group_gather_framebuffer_dealt(srx_group* g, srx_deal* deal, float* d_accum4, float* d_aux4) {
+    if (!g || !deal || !d_accum4) SRX_FAIL("srx_group_gather_framebuffer_dealt: null argument");
+    float* frames[2] = {d_accum4, d_aux4};
+    return gather_rows_dealt(g, deal, frames, d_aux4 ? 2 : 1, 4);
+}
+
+extern "C" int srx_group_allgather_rows_dealt(srx_group* g, srx_deal* deal, float* d_frame, int32_t floats_per_pixel) {
+    if (!g || !deal || !d_frame) SRX_FAIL("srx_group_allgather_rows_dealt: null argument");
+    float* frames[1] = {d_frame};
+    return gather_rows_dealt(g, deal, frames, 1, floats_per_pixel);
+}
+
 extern "C" int srx_group_allreduce(srx_group* g, double* d_sums, uint32_t n_sums, int32_t* d_mins, uint32_t n_mins) {
     if (!g) SRX_FAIL("srx_group_allreduce: null group");
     if ((n_sums && !d_sums) || (n_mins && !d_mins)) SRX_FAIL("srx_group_allreduce: null argument");

@@ -35,3 +35,22 @@ struct srx_scene {
     std::vector<uint8_t> tri_material_host;
 };
 
+
+// Noise-weighted dealing of the frame's row groups to the parts (ranks) of a job: csrc/srx_deal.hip.
+struct srx_deal {
+    int res_x = 0, res_y = 0, group = 0, nparts = 0, n_groups = 0;
+    std::vector<int> owner;                 // [n_groups]
+    std::vector<int> slot;                  // [n_groups]: index of the group in its owner's list
+    std::vector<std::vector<int>> lists;    // [nparts]: a part's groups, in its own order
+    std::vector<float> cost;                // [n_groups]: the burden of each group at the last rebalance (sum of its blocks' priorities)
+    uint32_t version = 1;
+    // device mirror, made on first use by a GPU call and refreshed after a rebalance: owner | slot | lists (concatenated)
+    int* d_tables = nullptr;
+    int d_device = -1;
+    uint32_t d_version = 0;
+    std::vector<int> list_off;              // [nparts + 1]: offsets of the lists in the concatenation
+};
+int srx_deal_rows_of_part(const srx_deal* d, int part);     // pixel rows a part owns
+int srx_deal_most_rows(const srx_deal* d);                  // the largest of those
+// device tables for `part` on the current device (uploads if stale): GRows fields list / owner, and the slot table
+int srx_deal_device(srx_deal* d, int part, const int** list, const int** owner, const int** slot);

@@ -113,9 +113,18 @@ extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hip
 // Rows of a pass: local row j of this caller is image row
 //   y0 + ((j / group) * nparts + part) * group + j % group
 // i.e. groups of `group` rows dealt round-robin over `nparts` callers (nparts == 1: the plain rectangle).
-struct GRows { int y0, group, nparts, part; };
+// With a deal (srx_deal, noise-weighted dealing of the row groups): `list` (device) = this part's groups in its own order
+// (a short last group of the frame is always last in its owner's list), `owner` (device) = the part every group belongs to;
+// local row j is then image row y0 + list[j / group] * group + j % group.
+struct GRows { int y0, group, nparts, part; const int* list = nullptr; const int* owner = nullptr; };
 __host__ __device__ inline int srx_row_of(const GRows& m, int j) {
+    if (m.list) return m.y0 + m.list[j / m.group] * m.group + (j % m.group);
     return m.y0 + ((j / m.group) * m.nparts + m.part) * m.group + (j % m.group);
+}
+__host__ __device__ inline bool srx_row_owned(const GRows& m, int y) {
+    const int rel = y - m.y0;
+    if (rel < 0) return false;
+    return m.owner ? m.owner[rel / m.group] == m.part : ((rel / m.group) % m.nparts) == m.part;
 }
 // rays for local rows [j0, j0 + rows) x columns [x0, x0 + w)
 extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, uint32_t pass_index,

@@ -32,8 +32,7 @@ __global__ __launch_bounds__(256) void k_noise_error(const float4* accum4, const
     int mine = 0x7fffffff;
     if (idx < n) {
         const int y = (int)(idx / (uint32_t)res_x);
-        const int rel = y - rm.y0;
-        const bool owned = rel >= 0 && ((rel / rm.group) % rm.nparts) == rm.part;
+        const bool owned = srx_row_owned(rm, y);
         float e = 0.0f;
         if (owned) {
             const float4 m = accum4[idx], a = aux4[idx];
@@ -237,12 +236,8 @@ extern "C" void srx_noise_destroy(srx_noise* c) {
     delete c;
 }
 
-extern "C" int srx_noise_error_map(srx_noise* c, const float* d_accum4, const float* d_aux4, int32_t group_rows, int32_t part,
-                                   int32_t nparts, float* d_err, int32_t* min_samples) {
-    if (!c || !d_accum4 || !d_aux4 || !d_err) SRX_FAIL("srx_noise_error_map: null argument");
-    if (group_rows <= 0 || nparts <= 0 || part < 0 || part >= nparts) SRX_FAIL("srx_noise_error_map: bad row interleave (group_rows, part, nparts)");
-    GRows rm;
-    rm.y0 = 0; rm.group = group_rows; rm.nparts = nparts; rm.part = part;
+namespace {
+int noise_error_map(srx_noise* c, const float* d_accum4, const float* d_aux4, const GRows& rm, float* d_err, int32_t* min_samples) {
     const int big = 0x7fffffff;
     SRX_HIP(hipMemcpy(c->d_min, &big, sizeof(int), hipMemcpyHostToDevice));
     const uint32_t n = (uint32_t)c->res_x * (uint32_t)c->res_y;
@@ -253,6 +248,27 @@ extern "C" int srx_noise_error_map(srx_noise* c, const float* d_accum4, const fl
     SRX_HIP(hipMemcpy(&mn, c->d_min, sizeof(int), hipMemcpyDeviceToHost));
     if (min_samples) *min_samples = (mn == big) ? 0 : mn;
     return 0;
+}
+}  // namespace
+
+extern "C" int srx_noise_error_map(srx_noise* c, const float* d_accum4, const float* d_aux4, int32_t group_rows, int32_t part,
+                                   int32_t nparts, float* d_err, int32_t* min_samples) {
+    if (!c || !d_accum4 || !d_aux4 || !d_err) SRX_FAIL("srx_noise_error_map: null argument");
+    if (group_rows <= 0 || nparts <= 0 || part < 0 || part >= nparts) SRX_FAIL("srx_noise_error_map: bad row interleave (group_rows, part, nparts)");
+    GRows rm;
+    rm.y0 = 0; rm.group = group_rows; rm.nparts = nparts; rm.part = part;
+    return noise_error_map(c, d_accum4, d_aux4, rm, d_err, min_samples);
+}
+
+// the same for the rows `part` owns under a deal (csrc/srx_deal.hip)
+extern "C" int srx_noise_error_map_dealt(srx_noise* c, const float* d_accum4, const float* d_aux4, srx_deal* deal, int32_t part, float* d_err,
+                                         int32_t* min_samples) {
+    if (!c || !d_accum4 || !d_aux4 || !d_err || !deal) SRX_FAIL("srx_noise_error_map_dealt: null argument");
+    if (deal->res_x != c->res_x || deal->res_y != c->res_y) SRX_FAIL("srx_noise_error_map_dealt: the deal was made for another frame size");
+    GRows rm;
+    rm.y0 = 0; rm.group = deal->group; rm.nparts = deal->nparts; rm.part = part;
+    if (srx_deal_device(deal, part, &rm.list, &rm.owner, nullptr)) return 1;
+    return noise_error_map(c, d_accum4, d_aux4, rm, d_err, min_samples);
 }
 
 extern "C" int srx_noise_analyze(srx_noise* c, const float* d_err, int32_t seen) {

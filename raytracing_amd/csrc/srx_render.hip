@@ -479,24 +479,16 @@ extern "C" int srx_trace_passes_interleaved(srx_renderer* r, const srx_camera* c
     return end_call(r, counters);
 }
 
-extern "C" int srx_trace_pass_adaptive(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
-                                       int32_t group_rows, int32_t part, int32_t nparts, uint32_t visit_index, uint64_t seed,
-                                       const float* d_block_priority, float* d_accum4, float* d_aux4, srx_counters* counters) {
-    if (!r || !camera || !d_accum4) SRX_FAIL("srx_trace_pass_adaptive: null argument");
-    if (camera->res_x <= 0 || camera->res_y <= 0 || camera->subdiv <= 0) SRX_FAIL("srx_trace_pass_adaptive: bad camera");
-    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > camera->res_x || y0 + h > camera->res_y)
-        SRX_FAIL("srx_trace_pass_adaptive: rectangle outside the camera resolution");
-    if (group_rows <= 0 || nparts <= 0 || part < 0 || part >= nparts) SRX_FAIL("srx_trace_pass_adaptive: bad row interleave (group_rows, part, nparts)");
+namespace {
+// One visit over the rows rm describes (own_rows of them), columns [x0, x0 + w).
+int trace_visit(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t w, const GRows& rm, int own_rows, uint32_t visit_index, uint64_t seed,
+                const float* d_block_priority, float* d_accum4, float* d_aux4, srx_counters* counters) {
     const uint64_t npix = (uint64_t)camera->res_x * camera->res_y;
     if (npix > 0x00FFFFFFull) SRX_FAIL("srx_trace_pass_adaptive: more than 2^24-1 pixels is not supported");
     if (begin_call(r)) return 1;
     if (ensure_sample_buffer(r, npix)) return 1;
     GCamera cam;
     std::memcpy(&cam, camera, sizeof(cam));
-    GRows rm;
-    rm.y0 = y0; rm.group = group_rows; rm.nparts = nparts; rm.part = part;
-    int own_rows = 0;
-    for (int g0 = part * group_rows; g0 < h; g0 += nparts * group_rows) own_rows += std::min(group_rows, h - g0);
     if (own_rows == 0) return end_call(r, counters);
     AdaptiveArgs a;
     a.block_priority = d_block_priority; a.accum4 = (const float4*)d_accum4; a.visit_index = visit_index; a.seed = seed;
@@ -522,6 +514,35 @@ extern "C" int srx_trace_pass_adaptive(srx_renderer* r, const srx_camera* camera
     if (join_shadows(r)) return 1;
     SRX_HIP(srx_launch_accumulate_adaptive(camera->res_x, x0, w, rm, own_rows, a, r->sample3, d_accum4, d_aux4, r->stream));
     return end_call(r, counters);
+}
+}  // namespace
+
+extern "C" int srx_trace_pass_adaptive(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                                       int32_t group_rows, int32_t part, int32_t nparts, uint32_t visit_index, uint64_t seed,
+                                       const float* d_block_priority, float* d_accum4, float* d_aux4, srx_counters* counters) {
+    if (!r || !camera || !d_accum4) SRX_FAIL("srx_trace_pass_adaptive: null argument");
+    if (camera->res_x <= 0 || camera->res_y <= 0 || camera->subdiv <= 0) SRX_FAIL("srx_trace_pass_adaptive: bad camera");
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > camera->res_x || y0 + h > camera->res_y)
+        SRX_FAIL("srx_trace_pass_adaptive: rectangle outside the camera resolution");
+    if (group_rows <= 0 || nparts <= 0 || part < 0 || part >= nparts) SRX_FAIL("srx_trace_pass_adaptive: bad row interleave (group_rows, part, nparts)");
+    GRows rm;
+    rm.y0 = y0; rm.group = group_rows; rm.nparts = nparts; rm.part = part;
+    int own_rows = 0;
+    for (int g0 = part * group_rows; g0 < h; g0 += nparts * group_rows) own_rows += std::min(group_rows, h - g0);
+    return trace_visit(r, camera, x0, w, rm, own_rows, visit_index, seed, d_block_priority, d_accum4, d_aux4, counters);
+}
+
+// The same visit over the rows `part` owns under a deal (csrc/srx_deal.hip): the whole frame's rows, dealt by burden.
+extern "C" int srx_trace_pass_adaptive_dealt(srx_renderer* r, const srx_camera* camera, srx_deal* deal, int32_t part, uint32_t visit_index, uint64_t seed,
+                                             const float* d_block_priority, float* d_accum4, float* d_aux4, srx_counters* counters) {
+    if (!r || !camera || !d_accum4 || !deal) SRX_FAIL("srx_trace_pass_adaptive_dealt: null argument");
+    if (camera->res_x <= 0 || camera->res_y <= 0 || camera->subdiv <= 0) SRX_FAIL("srx_trace_pass_adaptive_dealt: bad camera");
+    if (deal->res_x != camera->res_x || deal->res_y != camera->res_y) SRX_FAIL("srx_trace_pass_adaptive_dealt: the deal was made for another frame size");
+    if (part < 0 || part >= deal->nparts) SRX_FAIL("srx_trace_pass_adaptive_dealt: part out of range");
+    GRows rm;
+    rm.y0 = 0; rm.group = deal->group; rm.nparts = deal->nparts; rm.part = part;
+    if (srx_deal_device(deal, part, &rm.list, &rm.owner, nullptr)) return 1;
+    return trace_visit(r, camera, 0, camera->res_x, rm, srx_deal_rows_of_part(deal, part), visit_index, seed, d_block_priority, d_accum4, d_aux4, counters);
 }
 
 extern "C" int srx_trace_pass(srx_renderer* r, const srx_camera* camera, int32_t x0, int32_t y0, int32_t w, int32_t h,

@@ -215,14 +215,20 @@ class RayEngine:
         return rad, ctr.as_dict()
 
     def trace_visit(self, camera, rect, visit_index, seed, accum4, aux4=None, block_priority=None, ray_capacity=1 << 22,
-                    interleave=None):
+                    interleave=None, deal=None, part=0):
         """One visit of every 4x4 block (`RenderThread::process_iteratively`, SceneManager.h:193-237) with the
         controller's block priorities (device tensor, None = all 1): a block takes a sample with probability
         `priority`; a pixel's sample index is its own count so far."""
         cam = np.ascontiguousarray(camera)
+        ctr = SrxCounters()
+        if deal is not None:
+            # the whole frame's rows as `deal` (tiles.Deal) gives them to `part`: srx_trace_pass_adaptive_dealt
+            check(self.L.srx_trace_pass_adaptive_dealt(self.renderer(ray_capacity), _p(cam), deal.h, C.c_int32(part), C.c_uint32(visit_index),
+                                                       C.c_uint64(seed), _dev_ptr(block_priority), _dev_ptr(accum4), _dev_ptr(aux4),
+                                                       C.byref(ctr)), "srx_trace_pass_adaptive_dealt")
+            return ctr.as_dict()
         x0, y0, w, h = rect
         group, part, nparts = interleave if interleave is not None else (max(1, h), 0, 1)
-        ctr = SrxCounters()
         check(self.L.srx_trace_pass_adaptive(self.renderer(ray_capacity), _p(cam), C.c_int32(x0), C.c_int32(y0), C.c_int32(w),
                                              C.c_int32(h), C.c_int32(group), C.c_int32(part), C.c_int32(nparts),
                                              C.c_uint32(visit_index), C.c_uint64(seed), _dev_ptr(block_priority), _dev_ptr(accum4),
@@ -317,11 +323,15 @@ class NoiseController:
     def n_blocks(self):
         return ((self.res_x + 3) // 4) * ((self.res_y + 3) // 4)
 
-    def error_map(self, accum4, aux4, err, interleave=None):
+    def error_map(self, accum4, aux4, err, interleave=None, deal=None, part=0):
         """Fills `err` (device, one float per pixel) for this caller's rows, 0 elsewhere; returns the minimum sample
-        count of those rows (SceneManager.h:492-501, :566-572)."""
-        group, part, nparts = interleave if interleave is not None else (self.res_y, 0, 1)
+        count of those rows (SceneManager.h:492-501, :566-572). `deal` (tiles.Deal) + `part`: the rows a deal gives it."""
         mn = C.c_int32(0)
+        if deal is not None:
+            check(self.L.srx_noise_error_map_dealt(self.h, _dev_ptr(accum4), _dev_ptr(aux4), deal.h, C.c_int32(part), _dev_ptr(err),
+                                                   C.byref(mn)), "srx_noise_error_map_dealt")
+            return mn.value
+        group, part, nparts = interleave if interleave is not None else (self.res_y, 0, 1)
         check(self.L.srx_noise_error_map(self.h, _dev_ptr(accum4), _dev_ptr(aux4), C.c_int32(group), C.c_int32(part),
                                          C.c_int32(nparts), _dev_ptr(err), C.byref(mn)), "srx_noise_error_map")
         return mn.value

@@ -132,6 +132,107 @@ def _gather_interleaved(bufs, height, width, tile):
     return bufs
 
 
+# ---------------------------------------------------------------- noise-weighted dealing of the tile rows (csrc/srx_deal.hip)
+class Deal:
+    """`srx_deal` of include/srx.h: which rank owns which tile row. Starts as the round-robin of `interleaved_rows`
+    (`SceneManager::assign_iterative_groups`, SceneManager.h:441-459); `rebalance(block_priority)` re-deals the rows the way
+    `SceneManager::balance_threads` (:693-773) re-deals blocks to threads, until the ranks' burdens (sums of block
+    priorities) are within 5 %. A function of the priorities alone, so every rank computes the same deal; host code, works
+    without a GPU."""
+
+    def __init__(self, res_x, res_y, nparts, tile=TILE):
+        import ctypes as C
+        from . import _lib
+        self.L, self.C, self._check = _lib.lib(), C, _lib.check
+        self.h = C.c_void_p()
+        self._check(self.L.srx_deal_create(C.c_int32(res_x), C.c_int32(res_y), C.c_int32(tile), C.c_int32(nparts), C.byref(self.h)), "srx_deal_create")
+        self.res_x, self.res_y, self.nparts, self.tile = int(res_x), int(res_y), int(nparts), int(tile)
+        self.n_groups = (self.res_y + tile - 1) // tile
+        self._rows = {}
+
+    def close(self):
+        if self.h:
+            self.L.srx_deal_destroy(self.h)
+            self.h = self.C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rebalance(self, block_priority) -> int:
+        """`block_priority`: the controller's priorities (torch tensor on any device, or an array), one per 4x4 block.
+        Returns how many tile rows changed hands."""
+        import numpy as np
+        C = self.C
+        pr = block_priority.detach().cpu().numpy() if hasattr(block_priority, "detach") else np.asarray(block_priority)
+        pr = np.ascontiguousarray(pr, np.float32)
+        moved = C.c_int32(0)
+        self._check(self.L.srx_deal_rebalance(self.h, pr.ctypes.data_as(C.c_void_p), C.c_uint32(pr.size), C.byref(moved)), "srx_deal_rebalance")
+        self._rows = {}
+        return int(moved.value)
+
+    def tables(self):
+        """(owner[n_groups], slot[n_groups], burdens[nparts]) as numpy arrays."""
+        import numpy as np
+        C = self.C
+        owner = np.zeros(self.n_groups, np.int32); slot = np.zeros(self.n_groups, np.int32); burdens = np.zeros(self.nparts, np.float32)
+        n = C.c_uint32(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self.L.srx_deal_get(self.h, p(owner), p(slot), C.c_uint32(self.n_groups), C.byref(n), p(burdens)), "srx_deal_get")
+        return owner, slot, burdens
+
+    def groups_of(self, part):
+        """The tile rows of `part` in the order it renders and packs them."""
+        import numpy as np
+        owner, slot, _ = self.tables()
+        g = np.nonzero(owner == part)[0]
+        return g[np.argsort(slot[g])]
+
+    def rows_of(self, part) -> torch.Tensor:
+        """Image rows of `part`, in the order of its packed share."""
+        if part not in self._rows:
+            rows = []
+            for g in self.groups_of(part):
+                rows.extend(range(int(g) * self.tile, min(self.res_y, (int(g) + 1) * self.tile)))
+            self._rows[part] = torch.tensor(rows, dtype=torch.long)
+        return self._rows[part]
+
+
+def gather_framebuffer_dealt(buf, deal: Deal):
+    """`gather_framebuffer_interleaved` under a deal, over torch.distributed (gloo tests and rehearsals; on GPUs
+    `Group.gather_framebuffer_dealt` does it through the library): every rank's rows, in its deal order, padded to the
+    largest share, ONE all-gather for all the buffers, one indexed copy back."""
+    bufs = list(buf) if isinstance(buf, (list, tuple)) else [buf]
+    if not _is_dist() or not bufs:
+        return buf
+    staged = bufs[0].is_cuda and dist.get_backend() == "gloo"
+    work = [b.cpu() for b in bufs] if staged else bufs
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world != deal.nparts:
+        raise ValueError(f"the deal has {deal.nparts} parts, the job {world} ranks")
+    H = deal.res_y
+    views = [b.view(H, -1) for b in work]
+    cols = views[0].shape[1]
+    owned = [deal.rows_of(r).to(work[0].device) for r in range(world)]
+    most = max(len(o) for o in owned)
+    nb = len(views)
+    mine = torch.zeros((nb, most, cols), dtype=work[0].dtype, device=work[0].device)
+    for i, v in enumerate(views):
+        mine[i, : len(owned[rank])] = v[owned[rank]]
+    everyone = torch.empty((world, nb, most, cols), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(everyone.view(world * nb * most, cols), mine.view(nb * most, cols))
+    for i, v in enumerate(views):
+        for r in range(world):
+            if r != rank:
+                v[owned[r]] = everyone[r, i, : len(owned[r])]
+    if staged:
+        for b, h in zip(bufs, work):
+            b.copy_(h)
+    return buf
+
+
 # ---------------------------------------------------------------- the C-ABI exchange (csrc/srx_group.hip)
 class Group:
     """`srx_group` of include/srx.h: the exchange steps through the library itself (RCCL loaded by libsrx.so, row
@@ -202,6 +303,12 @@ class Group:
         self._check(self.L.srx_group_allgather_rows(self.h, self._ptr(frame), C.c_int32(floats_per_pixel), C.c_int32(width), C.c_int32(height),
                                                     C.c_int32(tile)), "srx_group_allgather_rows")
 
+    def gather_framebuffer_dealt(self, deal, accum4, aux4):
+        self._check(self.L.srx_group_gather_framebuffer_dealt(self.h, deal.h, self._ptr(accum4), self._ptr(aux4)), "srx_group_gather_framebuffer_dealt")
+
+    def allgather_rows_dealt(self, deal, frame, floats_per_pixel):
+        self._check(self.L.srx_group_allgather_rows_dealt(self.h, deal.h, self._ptr(frame), self.C.c_int32(floats_per_pixel)), "srx_group_allgather_rows_dealt")
+
     def allreduce(self, sums=None, mins=None):
         """In place: `sums` (float64 device tensor) summed over the ranks, `mins` (int32 device tensor) minimised."""
         C = self.C
@@ -236,6 +343,25 @@ def rows_pack_unpack_roundtrip(frames_by_part, floats_per_pixel, height, width, 
     out = torch.full_like(frames_by_part[0], float("nan"))
     _lib.check(L.srx_rows_unpack(C.c_void_p(slots.data_ptr()), C.c_uint64(slot), C.c_uint64(0), C.c_int32(floats_per_pixel), C.c_int32(width),
                                  C.c_int32(height), C.c_int32(tile), C.c_int32(n), C.c_int32(-1), C.c_void_p(out.data_ptr()), None), "srx_rows_unpack")
+    torch.cuda.synchronize()
+    return out
+
+
+def rows_pack_unpack_roundtrip_dealt(frames_by_part, floats_per_pixel, deal: Deal):
+    """`rows_pack_unpack_roundtrip` under a deal (srx_rows_pack_dealt / srx_rows_unpack_dealt on ONE GPU)."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    n = len(frames_by_part)
+    slot = int(L.srx_deal_slot_floats(deal.h, C.c_int32(floats_per_pixel)))
+    slots = torch.full((n * slot,), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for p, f in enumerate(frames_by_part):
+        _lib.check(L.srx_rows_pack_dealt(deal.h, C.c_void_p(f.data_ptr()), C.c_int32(floats_per_pixel), C.c_int32(p),
+                                         C.c_void_p(slots.data_ptr() + 4 * p * slot), None), "srx_rows_pack_dealt")
+    out = torch.full_like(frames_by_part[0], float("nan"))
+    _lib.check(L.srx_rows_unpack_dealt(deal.h, C.c_void_p(slots.data_ptr()), C.c_uint64(slot), C.c_uint64(0), C.c_int32(floats_per_pixel), C.c_int32(-1),
+                                       C.c_void_p(out.data_ptr()), None), "srx_rows_unpack_dealt")
     torch.cuda.synchronize()
     return out
 

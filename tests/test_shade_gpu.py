@@ -26,10 +26,12 @@ def _scenes():
         # C5 (BASELINE.json configs[4]): closed diffuse box + clutter, 16 generations, monte_carlo_max 1, no sun
         "diffuse_box": lambda: scenes.diffuse_box(3000, res=(64, 36), subdiv=2),
         "interior_npot": lambda: scenes.interior(6000, res=(64, 36), subdiv=2, tex_size=50),
+        # C5 "and also 32" (Scene.h:29): the same box with the reference's default fan-out 32 / 8 / 2, then 13 generations of 1
+        "diffuse_box_mcm32": lambda: scenes.diffuse_box(3000, res=(48, 27), subdiv=2, monte_carlo_max=32),
     }
 
 
-@pytest.fixture(scope="module", params=["cornell", "atrium", "interior", "diffuse_box", "interior_npot"])
+@pytest.fixture(scope="module", params=["cornell", "atrium", "interior", "diffuse_box", "interior_npot", "diffuse_box_mcm32"])
 def loaded(request, tables):
     from oracle import sro
     from raytracing_amd import engine
