@@ -125,15 +125,15 @@ __device__ __forceinline__ float x86_max(float a, float b) { return a > b ? a : 
 // z = fma(0, 1/d, -o/d), which is -o/d itself up to the sign of a zero (a zero result is "no hit" either way).
 //   Filter: a leaf is skipped (may_hit false) when BOTH hold: (1) the stored box's interval, widened by pt on both
 // ends, is empty or behind the ray, with pt = SRX_FILTER_PAD_REL x the largest coordinate distance from the ray's origin
-// to the box (max|t_plane| |d_axis|, in units of t: c1 = SRX_FILTER_PAD_REL max|1/d|) + floor_t, the absolute part
+// to the box (max|t_plane| |d_axis|, in units of t: c1 = SRX_FILTER_PAD_REL max|1/d|; the caller passes cd = |d| c1) + floor_t, the absolute part
 // (SRX_FILTER_PAD_ABS x (scene size + max|o|) max|1/d|; infinite for rays that are never filtered); (2) the ray keeps clear of the planes of
 // all the leaf's triangles, |a . dq| >= 127 h with the leaf's cone word (srx_device.h): near such a plane the
 // reference's triangle test divides by a det that is rounding noise and can accept far outside the padded box
 // (tests/test_leaf_filter_*.py). An inner child that the reference test accepts always passes (1)
 // and its cone word is 0 (a = 0, h = 0: (2) holds trivially).
 template <bool FAST>
-__device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, const f3 inv, const f3 fused, const f3 d, const int dq,
-                                              const float c1, const float floor_t, bool& may_hit) {
+__device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, const f3 inv, const f3 fused, const f3 cd, const int dq,
+                                              const float floor_t, bool& may_hit) {
     const float tx1 = __fmaf_rn(A.x, inv.x, fused.x), tx2 = __fmaf_rn(A.w, inv.x, fused.x);
     const float ty1 = __fmaf_rn(A.y, inv.y, fused.y), ty2 = __fmaf_rn(B.x, inv.y, fused.y);
     const float tz1 = __fmaf_rn(A.z, inv.z, fused.z), tz2 = __fmaf_rn(B.y, inv.z, fused.z);
@@ -149,7 +149,7 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, co
     const int sd = __builtin_amdgcn_sdot4((int)cone, dq, 0, false);
     const bool clear_of_planes = (uint32_t)abs(sd) >= (cone >> 24) * 127u;
 #endif
-    const float ex = hw_max_neg(nx, fx) * (fabsf(d.x) * c1), ey = hw_max_neg(ny, fy) * (fabsf(d.y) * c1), ez = hw_max_neg(nz, fz) * (fabsf(d.z) * c1);
+    const float ex = hw_max_neg(nx, fx) * cd.x, ey = hw_max_neg(ny, fy) * cd.y, ez = hw_max_neg(nz, fz) * cd.z;   // cd = |d| c1 per axis
     const float pt = hw_max3(ez, ey, ex) + floor_t;
     may_hit = (!(smin - smax > pt + pt) && !(smax < -pt)) || !clear_of_planes;
     float tmin, tmax;
@@ -178,6 +178,9 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, co
 }
 
 // MODE 0: closest hit.  MODE 1: shadow, API form (writes lit[]).  MODE 2: shadow, renderer queue form.
+// MODE 3: MODE 2 for a scene with ONE sun: every ray of the launch has the same direction (SunLight::vectorTo returns the
+// stored vector whatever the point, Primitives.h:39-51), so 1/d, |d| c1, the guard's quantised direction and d itself are
+// per-launch constants held in scalar registers instead of per-ray values in LDS and vector registers.
 // SPILL: the launch keeps a.lds_depth < sc.stack_depth entries per octet in LDS; the bottom half of an octet's LDS part
 // moves to the wave's overflow area in memory when a push might not fit, and comes back when the LDS part runs empty.
 template <int MODE, int K, bool SPILL>
@@ -218,6 +221,8 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         srx_trace_block_range<K>(layout, n_rays, lblock, block_start, cnt);
         block_rays = (int)cnt;
     }
+    constexpr bool SHQ = MODE >= 2;     // shadow rays of the renderer's queue
+    constexpr bool UNI = MODE == 3;     // ... that all share one direction
     float4* const s_setup = (float4*)(s_best + SRX_OCTETS_PER_BLOCK);   // [K][octets][3]: {d, o.x}, {o.yz, inv.xy}, {inv.z, fused}
     float2* const s_pt = (float2*)(s_setup + (size_t)K * SRX_OCTETS_PER_BLOCK * 3);   // [K][octets]: leaf filter widening, quantised direction (bits)
     uint32_t* const s_spilled = (uint32_t*)(s_pt + K * SRX_OCTETS_PER_BLOCK);   // [octets]: entries parked in memory (SPILL)
@@ -233,7 +238,9 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         if (mine) {
             const float* po = a.org + (size_t)myray * a.org_stride;
             so = f3(po[0], po[1], po[2]);
-            if (MODE == 2) {
+            if (UNI) {
+                sd = f3(sc.suns[0].dir[0], sc.suns[0].dir[1], sc.suns[0].dir[2]);
+            } else if (SHQ) {
                 const GSun& s = sc.suns[a.shadow_q[myray].pixel_sun >> 24];
                 sd = f3(s.dir[0], s.dir[1], s.dir[2]);
             } else {
@@ -281,13 +288,32 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const float4* ray_setup = s_setup;
     float c1 = 0.0f, floor_t = 0.0f;
     int dq = 0;
+    // UNI: the launch's one direction and what derives from it, in scalar registers (the same arithmetic as the per-ray
+    // set-up above, on the same numbers: d comes from the same GSun)
+    f3 u_d, u_cd;
+    if (UNI) {
+        const f3 ud(sc.suns[0].dir[0], sc.suns[0].dir[1], sc.suns[0].dir[2]);
+        const f3 ui = f3(1.0f) / ud;
+        const float uc1 = SRX_FILTER_PAD_REL * fmaxf(fmaxf(fabsf(ui.x), fabsf(ui.y)), fabsf(ui.z));
+        const float udd = __fmaf_rn(ud.z, ud.z, __fmaf_rn(ud.y, ud.y, ud.x * ud.x));
+        const float uq = 127.0f / sqrtf(udd);
+        const uint32_t udq = ((uint32_t)(int)rintf(ud.x * uq) & 255u) | (((uint32_t)(int)rintf(ud.y * uq) & 255u) << 8) | (((uint32_t)(int)rintf(ud.z * uq) & 255u) << 16);
+        auto sgpr = [](float x) { return u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(x))); };
+        u_d = f3(sgpr(ud.x), sgpr(ud.y), sgpr(ud.z));
+        inv = f3(sgpr(ui.x), sgpr(ui.y), sgpr(ui.z));
+        u_cd = f3(sgpr(fabsf(ud.x) * uc1), sgpr(fabsf(ud.y) * uc1), sgpr(fabsf(ud.z) * uc1));
+        dq = __builtin_amdgcn_readfirstlane((int)udq);
+    }
     auto load_ray_j = [&](int j) {
         ray_setup = s_setup + (size_t)j * 3;
-        const float2 r1 = *(const float2*)((const char*)ray_setup + 24);
         const float4 r2 = ray_setup[2];
         const float2 pq = s_pt[j];
-        floor_t = pq.x; dq = (int)f2u(pq.y); inv = f3(r1.x, r1.y, r2.x); fused = f3(r2.y, r2.z, r2.w);
-        c1 = SRX_FILTER_PAD_REL * fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
+        floor_t = pq.x; fused = f3(r2.y, r2.z, r2.w);
+        if (!UNI) {
+            const float2 r1 = *(const float2*)((const char*)ray_setup + 24);
+            dq = (int)f2u(pq.y); inv = f3(r1.x, r1.y, r2.x);
+            c1 = SRX_FILTER_PAD_REL * fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
+        }
     };
     load_ray_j(oct);
 
@@ -320,7 +346,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 a.lit[r] = best_t > 9999.0f ? 1 : 0;
             }
         }
-        if (MODE == 2 && sub < 3 && best_t > 9999.0f) {
+        if (SHQ && sub < 3 && best_t > 9999.0f) {
             const GShadow& s = a.shadow_q[r];
             const float c = sub == 0 ? s.cr : (sub == 1 ? s.cg : s.cb);
             if (c != 0.0f) atomicAdd(&a.sample3[3 * (size_t)(s.pixel_sun & 0x00FFFFFFu) + sub], c);
@@ -342,10 +368,19 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         // pop until an entry survives the distance cull (Core.h:63-68)
         uint32_t link = 0;
         bool go = false;
-        while (sp >= 0) {
+        if (MODE == 0) {
+            while (sp >= 0) {
+                const unsigned long long e = s_stack[sp * SRX_OCTETS_PER_BLOCK + oct];
+                sp--;
+                if (!(u2f((uint32_t)(e >> 32)) >= best_t)) { link = (uint32_t)e; go = true; break; }
+            }
+        } else if (sp >= 0) {
+            // shadow rays: best_t stays at the miss distance until an occluder ends the ray (or, in a scene larger than
+            // 9999 units, a hit beyond 9999 is found), so the cull almost never fires: ONE pop per trip, and an octet
+            // whose entry is culled sits this trip out (same entries visited, same results, no inner loop)
             const unsigned long long e = s_stack[sp * SRX_OCTETS_PER_BLOCK + oct];
             sp--;
-            if (!(u2f((uint32_t)(e >> 32)) >= best_t)) { link = (uint32_t)e; go = true; break; }
+            if (!(u2f((uint32_t)(e >> 32)) >= best_t)) { link = (uint32_t)e; go = true; }
         }
         if (go) {
             const bool leaf = (link & SRX_LINK_LEAF) != 0u;
@@ -361,13 +396,14 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             const float4 B = *(const float4*)(rec + 128);   // {max.y, max.z, link, cone} / {e1.y, e1.z, e2.x, 0}
 #endif
             const float4 r0 = ray_setup[0];                 // the ray's direction (and o.x): both kinds of trip need it
-            const f3 d(r0.x, r0.y, r0.z);
+            const f3 d = UNI ? u_d : f3(r0.x, r0.y, r0.z);
             __builtin_amdgcn_s_setprio(0);
             if (!leaf) {
                 n_nodes++;
                 bool may_hit;
-                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused, d, dq, c1, floor_t, may_hit)
-                                         : node_test<false>(A, B, inv, fused, d, dq, c1, floor_t, may_hit);
+                const f3 cd = UNI ? u_cd : f3(fabsf(d.x) * c1, fabsf(d.y) * c1, fabsf(d.z) * c1);
+                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused, cd, dq, floor_t, may_hit)
+                                         : node_test<false>(A, B, inv, fused, cd, dq, floor_t, may_hit);
                 // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id. result==0 (either sign) is "no hit";
                 // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86): both together are
                 // |result| > (lane == 0 ? 7 : 0)
@@ -536,12 +572,19 @@ template <int K, bool SPILL>
 static void launch_k(int mode, uint32_t blocks, size_t lds, const GScene& sc, const TraceArgs& a, hipStream_t stream) {
     if (mode == 0) hipLaunchKernelGGL((k_trace<0, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
     else if (mode == 1) hipLaunchKernelGGL((k_trace<1, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
-    else hipLaunchKernelGGL((k_trace<2, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_trace<2, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
+    else hipLaunchKernelGGL((k_trace<3, K, SPILL>), dim3(blocks), dim3(SRX_TRACE_THREADS), lds, stream, sc, a);
 }
 
 extern "C" hipError_t srx_launch_trace(int mode, const GScene& sc, const TraceArgs& args, hipStream_t stream) {
     if (args.n == 0) return hipSuccess;
     TraceArgs a = args;
+    // the renderer's shadow rays of a scene with one sun all share its direction: the form that keeps it in scalar registers
+    // (SRX_SHADOW_UNIFORM=0: the general form, for A/B runs and tests)
+    if (mode == 2 && sc.n_suns == 1) {
+        const char* e = getenv("SRX_SHADOW_UNIFORM");      // read per launch: tests switch it between renderers of one process
+        if (!e || atoi(e) != 0) mode = 3;
+    }
     // Rays per octet for a form of the kernel: the most whose LDS footprint lets 32 waves share a CU, fewer for a launch
     // that cannot fill the chip's 8 192 wave slots (256 CUs x 32) with that many (more waves, each a shorter serial
     // chain: the last generations of a pass are launches of a few thousand rays).

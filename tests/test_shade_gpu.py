@@ -234,6 +234,34 @@ def test_shadow_stream_on_and_off_give_the_same_pass(loaded, monkeypatch):
     assert np.allclose(x1[:, :3], x0[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
 
 
+def test_uniform_direction_shadow_form_equals_the_general_form(loaded, monkeypatch):
+    """A scene with one sun sends every shadow ray of the renderer in the same direction (SunLight::vectorTo,
+    Primitives.h:39-51): k_trace<3> keeps that direction, its reciprocal, the leaf filter's per-axis widening factors and
+    the guard's quantised direction in scalar registers. SRX_SHADOW_UNIFORM=0 runs the general form (k_trace<2>, per-ray
+    values from LDS). Same shadow answers: same counters, node and packet tests included, same image."""
+    import torch
+    from raytracing_amd import engine
+    name, desc, RE, S = loaded
+    if len(desc.suns) != 1:
+        pytest.skip("the uniform form is for scenes with exactly one sun")
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SRX_SHADOW_UNIFORM", flag)
+        acc = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+        cs = [RE.trace_pass(cam, (0, 0, w, h), p, 17, acc, None) for p in range(2)]
+        torch.cuda.synchronize()
+        out.append((acc.cpu().numpy(), cs))
+    (a1, c1), (a0, c0) = out
+    for ca, cb in zip(c1, c0):
+        for k in ("rays_processed", "shadows_cast", "nodes", "packets", "shadow_nodes", "shadow_packets", "hits"):
+            assert int(ca[k]) == int(cb[k]), k
+        assert int(ca["shadows_cast"]) > 0
+    assert np.array_equal(a1[:, 3], a0[:, 3])
+    assert np.allclose(a1[:, :3], a0[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
+
+
 @pytest.mark.parametrize("mcm,cap", [(1, 1 << 12), (1, 1 << 11), (32, 1 << 15)])
 def test_chains_back_to_back(tables, monkeypatch, mcm, cap):
     """Chain mode (generations of fan-out 1 enqueued back to back, counts read on the device, csrc/srx_render.hip
