@@ -187,9 +187,10 @@ template <int MODE, int K, bool SPILL>
 __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArgs a) {
     // LDS: traversal stack [depth][octets of the block] of (tmin bits << 32 | link), then one 16-B best-hit record per octet
     extern __shared__ unsigned long long s_mem[];
-    unsigned long long* const s_stack = s_mem;
+    // one unused row below the stack, so that the entry under an octet's only entry can be read without a bounds test
+    unsigned long long* const s_stack = s_mem + SRX_OCTETS_PER_BLOCK;
     const int D = a.lds_depth;
-    uint4* const s_best = (uint4*)(s_mem + (size_t)D * SRX_OCTETS_PER_BLOCK);
+    uint4* const s_best = (uint4*)(s_stack + (size_t)D * SRX_OCTETS_PER_BLOCK);
     const int sub = threadIdx.x & 7;
     const int oct = threadIdx.x >> 3;
     const int lane = threadIdx.x & 63;
@@ -369,10 +370,19 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         uint32_t link = 0;
         bool go = false;
         if (MODE == 0) {
-            while (sp >= 0) {
-                const unsigned long long e = s_stack[sp * SRX_OCTETS_PER_BLOCK + oct];
-                sp--;
-                if (!(u2f((uint32_t)(e >> 32)) >= best_t)) { link = (uint32_t)e; go = true; break; }
+            // the top TWO entries in one LDS round trip (Core.h:63-68 pops until an entry survives the cull: a loop of
+            // dependent LDS reads here, 1.4 of them per trip on average); an octet whose top two entries are both culled
+            // drops them and sits this trip out. Same entries, same order, same results. Measured on the bench workload,
+            // kernel alone: 24.0 ms per pass against 24.55 with the loop, and 25.0 with the loop kept for the third entry on.
+            if (sp >= 0) {
+                const unsigned long long e1 = s_stack[sp * SRX_OCTETS_PER_BLOCK + oct];
+                const unsigned long long e2 = s_stack[(sp - 1) * SRX_OCTETS_PER_BLOCK + oct];
+                const bool ok1 = !(u2f((uint32_t)(e1 >> 32)) >= best_t);
+                const bool ok2 = sp >= 1 && !(u2f((uint32_t)(e2 >> 32)) >= best_t);
+                link = ok1 ? (uint32_t)e1 : (uint32_t)e2;
+                go = ok1 || ok2;
+                sp -= ok1 ? 1 : 2;
+                if (sp < -1) sp = -1;
             }
         } else if (sp >= 0) {
             // shadow rays: best_t stays at the miss distance until an occluder ends the ray (or, in a scene larger than
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
 }
 
 static size_t trace_lds_bytes(int lds_depth, int k, bool spill) {
-    return (size_t)lds_depth * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
+    return (size_t)(lds_depth + 1) * SRX_OCTETS_PER_BLOCK * sizeof(unsigned long long) + SRX_OCTETS_PER_BLOCK * sizeof(uint4) +
            (size_t)SRX_OCTETS_PER_BLOCK * k * (3 * sizeof(float4) + sizeof(float2)) + (spill ? SRX_OCTETS_PER_BLOCK * sizeof(uint32_t) : 0);
 }
 
