@@ -520,6 +520,10 @@ def main():
         print(json.dumps(out), flush=True)
     RE.close()
     if world > 1:
+        if NCx is not None:
+            NCx.close()
+        if grp is not None:
+            grp.close()             # the library's communicator goes before torch's, and not at interpreter shutdown
         dist.destroy_process_group()
 
 
