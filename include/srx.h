@@ -14,6 +14,7 @@
  */
 #ifndef SRX_H
 #define SRX_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -323,8 +324,9 @@ int srx_gltf_get(const srx_gltf* g, const srx_tri** tris, uint32_t* n_tris, cons
                  const srx_texture** textures, uint32_t* n_textures, const srx_sun** suns, uint32_t* n_suns, srx_camera* camera);
 /* The image decoder the loader uses, on its own: replaces stbi_load_from_memory(..., req_comp = 4) as tinygltf's
  * LoadImageData calls it for every embedded image (FileLoading.h:438 goes through tinygltf::TinyGLTF::LoadBinaryFromFile;
- * stb_image.h:1399, 3865-4026 for JPEG). 8-bit non-interlaced PNG and baseline / extended-sequential Huffman JPEG
- * (1 or 3 components, any sampling factors that divide the largest); JPEG bytes equal stb_image's. Writes width and
+ * stb_image.h:1399, 3865-4026 for JPEG). PNG of every colour type and bit depth (1-16), plain or Adam7-interlaced, with
+ * tRNS; baseline, extended-sequential and progressive Huffman JPEG (1 or 3 components, any sampling factors that divide
+ * the largest); the bytes equal stb_image's. Arithmetic-coded, lossless, 12-bit and CMYK JPEG are refused. Writes width and
  * height; when rgba is not NULL also width * height * 4 bytes (refused if capacity is smaller). Host-only. */
 int srx_image_decode(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint8_t* rgba, size_t capacity);
 

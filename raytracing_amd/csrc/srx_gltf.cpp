@@ -5,7 +5,7 @@
 // 423-434) with Object::compile_scale (:462-471) and Transformation::collpase (Transformation.h:28-57).
 //
 // The reference reads the file with tinygltf (a third-party header, not restated: this file has its own JSON and GLB
-// reader) and decodes embedded images with stb_image; here images are 8-bit non-interlaced PNG (own inflate) or baseline
+// reader) and decodes embedded images with stb_image; here images are PNG (own inflate; every depth, Adam7, tRNS) or Huffman-coded
 // JPEG (own decoder following stb_image's arithmetic, checked against it), any other image fails loudly. Reference behaviour kept on purpose (each is what the author's scenes were exported for):
 //  * axis swizzle (x, -z, y) for positions, normals and translations, (x, z, y) for scales, (x, -z, y, w) for
 //    rotations (:450-452); uv -> (u, 1 - v) (:658-660); emissive x 25 (:473); sun emission = color * intensity / 50000
@@ -297,11 +297,15 @@ std::vector<uint8_t> inflate_zlib(const uint8_t* d, size_t n, size_t max_out) {
 }
 
 struct Image { int w = 0, h = 0, comp = 0; std::vector<uint8_t> px; };   // comp 3 or 4, rows top to bottom (stb_image layout)
+// PNG as stb_image reads it with 4 components requested (stb_image.h:4600-5200): colour types 0 / 2 / 3 / 4 / 6, bit
+// depths 1 / 2 / 4 / 8 / 16 (gray below 8 bits is scaled to 0-255: x 255 / 85 / 17; 16-bit samples keep their HIGH byte),
+// Adam7 interlacing (seven sub-images, each filtered on its own), tRNS (palette alphas; a colour key for gray and RGB,
+// compared at the file's depth). Ancillary chunks are ignored.
 Image decode_png(const uint8_t* d, size_t n) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    if (n < 8 || std::memcmp(d, sig, 8)) fail("image is neither a PNG nor a JPEG (8-bit non-interlaced PNG and baseline JPEG images are decoded; the reference uses stb_image)");
-    Image im; int ctype = -1;
-    std::vector<uint8_t> z, plte;
+    if (n < 8 || std::memcmp(d, sig, 8)) fail("image is neither a PNG nor a JPEG (PNG and Huffman-coded JPEG images are decoded; the reference uses stb_image)");
+    Image im; int ctype = -1, depth = 0, interlace = 0;
+    std::vector<uint8_t> z, plte, trns;
     for (size_t at = 8; at + 12 <= n;) {
         const uint32_t len = (uint32_t)d[at] << 24 | d[at + 1] << 16 | d[at + 2] << 8 | d[at + 3];
         const char* ty = (const char*)d + at + 4;
@@ -311,65 +315,124 @@ Image decode_png(const uint8_t* d, size_t n) {
             if (len < 13) fail("PNG: bad IHDR");
             im.w = (int)((uint32_t)body[0] << 24 | body[1] << 16 | body[2] << 8 | body[3]);
             im.h = (int)((uint32_t)body[4] << 24 | body[5] << 16 | body[6] << 8 | body[7]);
-            ctype = body[9];
-            if (body[8] != 8 || body[12] != 0 || !(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 4 || ctype == 6))
-                fail("PNG: only 8-bit non-interlaced images are decoded");
+            depth = body[8]; ctype = body[9]; interlace = body[12];
+            if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) fail("PNG: bit depth must be 1, 2, 4, 8 or 16");
+            if (!(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 4 || ctype == 6)) fail("PNG: bad colour type");
+            if ((ctype == 3 && depth == 16) || ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8)) fail("PNG: bit depth not allowed for this colour type");
+            if (body[10] != 0 || body[11] != 0 || interlace > 1) fail("PNG: bad compression, filter or interlace method");
         } else if (!std::strncmp(ty, "PLTE", 4)) plte.assign(body, body + len);
+        else if (!std::strncmp(ty, "tRNS", 4)) trns.assign(body, body + len);
         else if (!std::strncmp(ty, "IDAT", 4)) z.insert(z.end(), body, body + len);
         else if (!std::strncmp(ty, "IEND", 4)) break;
         at += 12 + (size_t)len;
     }
     if (im.w <= 0 || im.h <= 0 || ctype < 0) fail("PNG: no IHDR");
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
-    const size_t stride = (size_t)im.w * ch;
     if ((uint64_t)im.w * (uint64_t)im.h > (1ull << 28)) fail("PNG: image larger than 2^28 pixels");
-    std::vector<uint8_t> raw = inflate_zlib(z.data(), z.size(), (stride + 1) * (size_t)im.h);
-    if (raw.size() < (stride + 1) * (size_t)im.h) fail("PNG: pixel data too short");
-    std::vector<uint8_t> img(stride * im.h);
-    for (int y = 0; y < im.h; y++) {
-        const uint8_t* in = raw.data() + (stride + 1) * y;
-        uint8_t* cur = img.data() + stride * y;
-        const uint8_t* up = y ? cur - stride : nullptr;
-        const int f = in[0];
-        for (size_t x = 0; x < stride; x++) {
-            const int a = x >= (size_t)ch ? cur[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
-            int v = in[1 + x];
-            switch (f) {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                      v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-            default: fail("PNG: bad filter");
+    // the sub-images: one, or Adam7's seven
+    static const int xorig[7] = {0, 4, 0, 2, 0, 1, 0}, yorig[7] = {0, 0, 4, 0, 2, 0, 1}, xspc[7] = {8, 8, 4, 4, 2, 2, 1}, yspc[7] = {8, 8, 8, 4, 4, 2, 2};
+    struct Pass { int w, h, x0, y0, dx, dy; size_t row_bytes; };
+    std::vector<Pass> passes;
+    size_t raw_need = 0;
+    for (int p = 0; p < (interlace ? 7 : 1); p++) {
+        Pass q;
+        if (interlace) { q.x0 = xorig[p]; q.y0 = yorig[p]; q.dx = xspc[p]; q.dy = yspc[p]; q.w = (im.w - q.x0 + q.dx - 1) / q.dx; q.h = (im.h - q.y0 + q.dy - 1) / q.dy; }
+        else { q.x0 = q.y0 = 0; q.dx = q.dy = 1; q.w = im.w; q.h = im.h; }
+        if (q.w <= 0 || q.h <= 0) continue;
+        q.row_bytes = ((size_t)ch * q.w * depth + 7) >> 3;
+        raw_need += (q.row_bytes + 1) * (size_t)q.h;
+        passes.push_back(q);
+    }
+    std::vector<uint8_t> raw = inflate_zlib(z.data(), z.size(), raw_need);
+    if (raw.size() < raw_need) fail("PNG: pixel data too short");
+    // samples at the file's depth (16-bit ones whole), `ch` per pixel
+    std::vector<uint16_t> smp((size_t)im.w * im.h * ch);
+    const int fb = depth == 16 ? 2 * ch : (depth == 8 ? ch : 1);      // bytes a filter looks back
+    size_t at = 0;
+    std::vector<uint8_t> cur_row, up_row;
+    for (const Pass& q : passes) {
+        cur_row.assign(q.row_bytes, 0); up_row.assign(q.row_bytes, 0);
+        for (int y = 0; y < q.h; y++) {
+            const uint8_t* in = raw.data() + at;
+            at += q.row_bytes + 1;
+            const int f = in[0];
+            if (f > 4) fail("PNG: bad filter");
+            for (size_t x = 0; x < q.row_bytes; x++) {
+                const int a = x >= (size_t)fb ? cur_row[x - fb] : 0, b2 = y ? up_row[x] : 0, c = (y && x >= (size_t)fb) ? up_row[x - fb] : 0;
+                int v = in[1 + x];
+                switch (f) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b2; break;
+                case 3: v += (a + b2) >> 1; break;
+                default: { const int pp = a + b2 - c, pa = std::abs(pp - a), pb = std::abs(pp - b2), pc = std::abs(pp - c);
+                           v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b2 : c); break; }
+                }
+                cur_row[x] = (uint8_t)v;
             }
-            cur[x] = (uint8_t)v;
+            const int oy = q.y0 + y * q.dy;
+            for (int x = 0; x < q.w; x++) {
+                uint16_t* o = smp.data() + ((size_t)oy * im.w + (size_t)(q.x0 + x * q.dx)) * ch;
+                for (int k = 0; k < ch; k++) {
+                    const size_t i = (size_t)x * ch + k;
+                    if (depth == 16) o[k] = (uint16_t)((cur_row[2 * i] << 8) | cur_row[2 * i + 1]);
+                    else if (depth == 8) o[k] = cur_row[i];
+                    else { const size_t bit = i * depth; o[k] = (uint16_t)((cur_row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1)); }
+                }
+            }
+            cur_row.swap(up_row);
         }
     }
-    // to RGB / RGBA like stb_image with req_comp 0 would give for colour images (tinygltf asks for 4 components: RGBA)
+    // to RGBA, 8 bits (tinygltf asks stb_image for 4 components)
+    const int gray_scale = depth == 1 ? 0xff : depth == 2 ? 0x55 : depth == 4 ? 0x11 : 1;      // stbi__depth_scale_table
+    bool has_key = false; uint16_t key[3] = {0, 0, 0};
+    if (!trns.empty() && (ctype == 0 || ctype == 2)) {
+        if (trns.size() != (size_t)(ctype == 0 ? 2 : 6)) fail("PNG: bad tRNS length");
+        has_key = true;
+        for (int k = 0; k < (ctype == 0 ? 1 : 3); k++) {
+            const uint16_t v = (uint16_t)((trns[2 * k] << 8) | trns[2 * k + 1]);
+            key[k] = depth == 16 ? v : (uint16_t)((v & 255) * gray_scale);                  // the 8-bit key is compared with the SCALED samples
+        }
+    }
+    if (ctype == 3 && (plte.empty() || plte.size() % 3 || plte.size() > 768)) fail("PNG: bad or missing palette");
+    if (ctype == 3 && trns.size() > plte.size() / 3) fail("PNG: tRNS longer than the palette");
     im.comp = 4;
     im.px.resize((size_t)im.w * im.h * 4);
+    auto to8 = [&](uint16_t v) { return (uint8_t)(depth == 16 ? (v >> 8) : v); };
     for (size_t i = 0; i < (size_t)im.w * im.h; i++) {
+        const uint16_t* sp = smp.data() + i * ch;
         uint8_t r, g, b, a = 255;
-        const uint8_t* s = img.data() + i * ch;
-        if (ctype == 0) { r = g = b = s[0]; }
-        else if (ctype == 4) { r = g = b = s[0]; a = s[1]; }
-        else if (ctype == 3) { if ((size_t)s[0] * 3 + 2 >= plte.size()) fail("PNG: palette index out of range"); r = plte[s[0] * 3]; g = plte[s[0] * 3 + 1]; b = plte[s[0] * 3 + 2]; }
-        else { r = s[0]; g = s[1]; b = s[2]; if (ctype == 6) a = s[3]; }
+        if (ctype == 3) {
+            const size_t idx = sp[0];
+            if (idx * 3 + 2 >= plte.size()) fail("PNG: palette index out of range");
+            r = plte[idx * 3]; g = plte[idx * 3 + 1]; b = plte[idx * 3 + 2];
+            if (idx < trns.size()) a = trns[idx];
+        } else if (ctype == 0 || ctype == 4) {
+            const uint16_t v = depth < 8 ? (uint16_t)(sp[0] * gray_scale) : sp[0];
+            r = g = b = to8(v);
+            if (ctype == 4) a = to8(sp[1]);
+            else if (has_key && v == key[0]) a = 0;
+        } else {
+            r = to8(sp[0]); g = to8(sp[1]); b = to8(sp[2]);
+            if (ctype == 6) a = to8(sp[3]);
+            else if (has_key && sp[0] == key[0] && sp[1] == key[1] && sp[2] == key[2]) a = 0;
+        }
         im.px[4 * i] = r; im.px[4 * i + 1] = g; im.px[4 * i + 2] = b; im.px[4 * i + 3] = a;
     }
     return im;
 }
 
-// ---------------------------------------------------------------- JPEG (baseline / extended sequential Huffman, 8 bits)
+// ---------------------------------------------------------------- JPEG (baseline / extended sequential / progressive Huffman, 8 bits)
 // The reference decodes images with stb_image 2.28 (through tinygltf, 4 components requested). Texel values feed the
 // shading, so the decoder follows stb_image's arithmetic step for step: the integer slow IDCT of jidctint with 12-bit
 // constants and stb's two extra bits between the passes, its chroma upsampling filters (h2v1: 3/4 + 1/4 across, h1v2:
 // the same down, h2v2: both, anything else: nearest) and its 20-bit fixed-point YCbCr -> RGB. tests/test_gltf_cpu.py
 // compares the decoded bytes with stb_image's own (oracle/_ref/ref_stb_probe, built from the reference's vendored header).
-// Progressive and arithmetic-coded files, 12-bit samples and CMYK fail loudly.
+// Progressive files (SOF2) are decoded like stb_image does it: coefficients accumulated over the scans, dequantised and
+// transformed at the end. Arithmetic-coded files, 12-bit samples and CMYK fail loudly.
 struct JpegHuff { uint8_t size[257]; uint16_t code[256]; uint8_t values[256]; int maxcode[18]; int delta[17]; int n = 0; bool set = false; };
-struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dc_pred = 0; int x = 0, y = 0, w2 = 0, h2 = 0; std::vector<uint8_t> data; };
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dc_pred = 0; int x = 0, y = 0, w2 = 0, h2 = 0; std::vector<uint8_t> data;
+                  std::vector<short> coeff; int coeff_w = 0; };     // progressive: the coefficients of every block, kept across the scans
 struct JpegDec {
     const uint8_t* d; size_t n, pos = 0;
     uint32_t code_buffer = 0; int code_bits = 0; int marker = -1; bool nomore = false;
@@ -380,6 +443,8 @@ struct JpegDec {
     int restart_interval = 0, todo = 0;
     int scan_n = 0, order[4];
     bool jfif = false; int app14 = -1; int rgb = 0;
+    // progressive (SOF2): spectral selection and successive approximation of the current scan, pending end-of-band run
+    bool progressive = false; int spec_start = 0, spec_end = 63, succ_high = 0, succ_low = 0, eob_run = 0;
 
     int get8() { return pos < n ? d[pos++] : 0; }
     int get16() { const int a = get8(); return (a << 8) | get8(); }
@@ -431,6 +496,119 @@ struct JpegDec {
         const unsigned v = code_buffer >> (32 - nb);
         code_buffer <<= nb; code_bits -= nb;
         return (int)v < (1 << (nb - 1)) ? (int)v - (1 << nb) + 1 : (int)v;
+    }
+    int get_bit() {                                                   // stb_image's stbi__jpeg_get_bit: 0 once the stream has run out
+        if (code_bits < 1) grow();
+        if (code_bits < 1) return 0;
+        const unsigned k = code_buffer;
+        code_buffer <<= 1; --code_bits;
+        return (int)(k >> 31);
+    }
+    int get_bits(int nb) {
+        if (nb == 0) return 0;
+        if (code_bits < nb) grow();
+        if (code_bits < nb) return 0;
+        const unsigned v = code_buffer >> (32 - nb);
+        code_buffer <<= nb; code_bits -= nb;
+        return (int)v;
+    }
+    // Progressive blocks (T.81 Annex G), in stb_image's order of operations (stb_image.h:2265-2397): a DC scan sets or
+    // refines data[0]; an AC scan fills or refines the band spec_start..spec_end, with end-of-band runs across blocks.
+    // Coefficients stay UNdequantised until the end (finish()).
+    void decode_block_prog_dc(short data[64], JpegComp& c) {
+        if (spec_end != 0) fail("JPEG: a progressive scan cannot carry DC and AC coefficients together");
+        if (code_bits < 16) grow();
+        if (succ_high == 0) {
+            std::memset(data, 0, 64 * sizeof(short));
+            const int t = huff(hdc[c.hd]);
+            if (t > 15) fail("JPEG: bad DC code");
+            const int diff = t ? extend_receive(t) : 0;
+            const long long dc = (long long)c.dc_pred + diff;
+            if (dc > 32767 || dc < -32768 || dc * (1LL << succ_low) > 32767 || dc * (1LL << succ_low) < -32768) fail("JPEG: DC coefficient out of range");
+            c.dc_pred = (int)dc;
+            data[0] = (short)(dc * (1 << succ_low));
+        } else if (get_bit()) {
+            data[0] = (short)(data[0] + (short)(1 << succ_low));
+        }
+    }
+    void decode_block_prog_ac(short data[64], JpegComp& c) {
+        static const uint8_t dezigzag[64 + 15] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+            63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+        if (spec_start == 0) fail("JPEG: a progressive scan cannot carry DC and AC coefficients together");
+        const JpegHuff& h = hac[c.ha];
+        if (succ_high == 0) {
+            const int shift = succ_low;
+            if (eob_run) { --eob_run; return; }
+            int k = spec_start;
+            do {
+                const int rs = huff(h);
+                const int sz = rs & 15, r = rs >> 4;
+                if (sz == 0) {
+                    if (r < 15) {
+                        eob_run = 1 << r;
+                        if (r) eob_run += get_bits(r);
+                        --eob_run;
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    const int zig = dezigzag[k++];
+                    data[zig] = (short)((uint32_t)extend_receive(sz) * (1u << shift));
+                }
+            } while (k <= spec_end);
+        } else {
+            const short bit = (short)(1 << succ_low);
+            auto refine = [&](short* p) {
+                if (get_bit() && (*p & bit) == 0) *p = (short)(*p > 0 ? *p + bit : *p - bit);
+            };
+            if (eob_run) {
+                --eob_run;
+                for (int k = spec_start; k <= spec_end; ++k) {
+                    short* p = &data[dezigzag[k]];
+                    if (*p != 0) refine(p);
+                }
+            } else {
+                int k = spec_start;
+                do {
+                    const int rs = huff(h);
+                    int sz = rs & 15, r = rs >> 4;
+                    if (sz == 0) {
+                        if (r < 15) {
+                            eob_run = (1 << r) - 1;
+                            if (r) eob_run += get_bits(r);
+                            r = 64;                                   // force the end of the block
+                        }                                             // (r = 15: a run of 16 zeros, nothing special to do)
+                    } else {
+                        if (sz != 1) fail("JPEG: bad huffman code");
+                        sz = get_bit() ? bit : -bit;
+                    }
+                    while (k <= spec_end) {
+                        short* p = &data[dezigzag[k++]];
+                        if (*p != 0) refine(p);
+                        else {
+                            if (r == 0) { *p = (short)sz; break; }
+                            --r;
+                        }
+                    }
+                } while (k <= spec_end);
+            }
+        }
+    }
+    // progressive: after the last scan, dequantise every block (in 16-bit arithmetic, as stb_image does) and transform it
+    void finish() {
+        for (int n2 = 0; n2 < ncomp; n2++) {
+            JpegComp& c = comp[n2];
+            const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+            const uint16_t* dq = dequant[c.tq];
+            for (int j = 0; j < h; j++)
+                for (int i = 0; i < w; i++) {
+                    short* data = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.coeff_w);
+                    for (int k = 0; k < 64; k++) data[k] = (short)((uint32_t)(int)data[k] * dq[k]);
+                    idct(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, data);
+                }
+        }
     }
     void decode_block(short data[64], JpegComp& c) {
         static const uint8_t dezigzag[64 + 15] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
@@ -508,7 +686,7 @@ struct JpegDec {
         }
     }
     void reset_entropy() {
-        code_bits = 0; code_buffer = 0; nomore = false; marker = -1;
+        code_bits = 0; code_buffer = 0; nomore = false; marker = -1; eob_run = 0;
         for (int i = 0; i < 4; i++) comp[i].dc_pred = 0;
         todo = restart_interval ? restart_interval : 0x7fffffff;
     }
@@ -523,6 +701,34 @@ struct JpegDec {
             }
             return true;
         };
+        if (progressive) {                                            // stb_image.h:3010-3070
+            if (scan_n == 1) {
+                JpegComp& c = comp[order[0]];
+                const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+                if (spec_start == 0 ? !hdc[c.hd].set : !hac[c.ha].set) fail("JPEG: scan uses a Huffman table that was not defined");
+                for (int j = 0; j < h; j++)
+                    for (int i = 0; i < w; i++) {
+                        short* blk = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.coeff_w);
+                        if (spec_start == 0) decode_block_prog_dc(blk, c); else decode_block_prog_ac(blk, c);
+                        if (!restart()) return;
+                    }
+            } else {                                                  // interleaved: DC only
+                for (int j = 0; j < mcu_y; j++)
+                    for (int i = 0; i < mcu_x; i++) {
+                        for (int k = 0; k < scan_n; k++) {
+                            JpegComp& c = comp[order[k]];
+                            if (!hdc[c.hd].set) fail("JPEG: scan uses a Huffman table that was not defined");
+                            for (int y = 0; y < c.v; y++)
+                                for (int x = 0; x < c.h; x++) {
+                                    const int x2 = i * c.h + x, y2 = j * c.v + y;
+                                    decode_block_prog_dc(c.coeff.data() + 64 * ((size_t)x2 + (size_t)y2 * c.coeff_w), c);
+                                }
+                        }
+                        if (!restart()) return;
+                    }
+            }
+            return;
+        }
         if (scan_n == 1) {                                            // one component: its own block grid, no MCU padding
             JpegComp& c = comp[order[0]];
             const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
@@ -551,7 +757,7 @@ struct JpegDec {
         }
     }
     void frame_header(int m) {
-        if (m == 0xc2) fail("JPEG: progressive files are not decoded (baseline only); re-export the texture as baseline JPEG or PNG");
+        progressive = m == 0xc2;
         const int lf = get16();
         if (lf < 11) fail("JPEG: bad SOF length");
         if (get8() != 8) fail("JPEG: only 8-bit samples are decoded");
@@ -583,6 +789,7 @@ struct JpegDec {
             comp[i].y = (img_y * comp[i].v + v_max - 1) / v_max;
             comp[i].w2 = mcu_x * comp[i].h * 8; comp[i].h2 = mcu_y * comp[i].v * 8;
             comp[i].data.assign((size_t)comp[i].w2 * comp[i].h2 + 15, 0);
+            if (progressive) { comp[i].coeff_w = comp[i].w2 / 8; comp[i].coeff.assign((size_t)comp[i].w2 * comp[i].h2 + 15, 0); }
         }
     }
     void scan_header() {
@@ -599,8 +806,15 @@ struct JpegDec {
             if (comp[which].hd > 3 || comp[which].ha > 3) fail("JPEG: bad Huffman table index");
             order[i] = which;
         }
-        const int ss = get8(); get8(); const int a = get8();
-        if (ss != 0 || a != 0) fail("JPEG: not a baseline scan");
+        spec_start = get8(); spec_end = get8();
+        const int a = get8();
+        succ_high = a >> 4; succ_low = a & 15;
+        if (progressive) {
+            if (spec_start > 63 || spec_end > 63 || spec_start > spec_end || succ_high > 13 || succ_low > 13) fail("JPEG: bad progressive scan parameters");
+        } else {
+            if (spec_start != 0 || a != 0) fail("JPEG: not a baseline scan");
+            spec_end = 63;
+        }
     }
     void marker_segment(int m) {
         if (m == 0xdd) { if (get16() != 4) fail("JPEG: bad DRI length"); restart_interval = get16(); return; }
@@ -693,6 +907,7 @@ Image decode_jpeg(const uint8_t* d, size_t n) {
         else z.marker_segment(m);
     }
     if (!seen_scan) fail("JPEG: no scan");
+    if (z.progressive) z.finish();
     // ---- upsample and convert, row by row (stb_image's load_jpeg_image with 4 components requested)
     Image im; im.w = z.img_x; im.h = z.img_y; im.comp = 4;
     im.px.resize((size_t)im.w * im.h * 4);

@@ -44,6 +44,71 @@ def png_bytes(img, filters=(0, 1, 2, 3, 4)):
             chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b""))
 
 
+def png_bytes_general(samples, depth, ctype, interlace=False, plte=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """Any PNG: `samples` (h, w, channels) integers at `depth` bits (1, 2, 4, 8, 16), colour type 0 / 2 / 3 / 4 / 6,
+    optional Adam7 interlacing, palette and tRNS chunk bodies; every row takes the next of the given filter types."""
+    h, w, c = samples.shape
+    assert c == {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    fb = 2 * c if depth == 16 else (c if depth == 8 else 1)
+
+    def pack(row):                                      # (w', c) samples -> bytes
+        flat = row.reshape(-1).astype(np.int64)
+        if depth == 16:
+            return np.stack([flat >> 8, flat & 255], -1).reshape(-1).astype(np.int32)
+        if depth == 8:
+            return flat.astype(np.int32)
+        per = 8 // depth
+        pad = (-len(flat)) % per
+        flat = np.concatenate([flat, np.zeros(pad, np.int64)]).reshape(-1, per)
+        shifts = np.array([8 - depth * (k + 1) for k in range(per)])
+        return (flat << shifts).sum(1).astype(np.int32)
+
+    raw = bytearray()
+    row_no = 0
+    passes = [(0, 0, 1, 1)] if not interlace else list(zip((0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)))
+    for x0, y0, dx, dy in passes:
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for y in range(sub.shape[0]):
+            cur = pack(sub[y])
+            f = filters[row_no % len(filters)]; row_no += 1
+            up = prev if prev is not None else np.zeros_like(cur)
+            out = np.zeros_like(cur)
+            for x in range(len(cur)):
+                a = cur[x - fb] if x >= fb else 0
+                b = up[x]
+                cc = up[x - fb] if x >= fb else 0
+                if f == 0:
+                    p = 0
+                elif f == 1:
+                    p = a
+                elif f == 2:
+                    p = b
+                elif f == 3:
+                    p = (a + b) >> 1
+                else:
+                    pp = a + b - cc
+                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - cc)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)
+                out[x] = (cur[x] - p) & 255
+            raw.append(f)
+            raw += bytes(out.astype(np.uint8))
+            prev = cur
+
+    def chunk(ty, body):
+        return struct.pack(">I", len(body)) + ty + body + struct.pack(">I", zlib.crc32(ty + body))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if plte is not None:
+        out += chunk(b"PLTE", bytes(plte))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    data = zlib.compress(bytes(raw), 6)
+    half = len(data) // 2                                # two IDAT chunks: the stream continues across them
+    return out + chunk(b"IDAT", data[:half]) + chunk(b"IDAT", data[half:]) + chunk(b"IEND", b"")
+
+
 class GlbWriter:
     def __init__(self):
         self.bin = bytearray()

@@ -6,7 +6,8 @@ oracle/_ref/libref_stb.so and asked for 4 components, as tinygltf does). Run in 
 
 Cases: 4:4:4, 4:2:2 (h2v1), 4:2:0 (h2v2), 4:4:0 (h1v2), 4:1:1 (h4v1: stb's nearest-neighbour path), grayscale, odd sizes
 down to 1x1, restart intervals, a 16-bit quantisation table (quality 1), an Adobe-marked RGB file (no colour transform),
-and a progressive file that the product must refuse."""
+progressive files (spectral selection + successive approximation, as libjpeg writes them; all three chroma layouts,
+grayscale, restart intervals), and PNGs of every colour type and bit depth, plain and Adam7-interlaced, with tRNS."""
 import ctypes as C
 import io
 import os
@@ -76,13 +77,17 @@ def main():
     cases["rgb_adobe_20x14"] = jpeg(picture(20, 14, 49), quality=90, subsampling=0, keep_rgb=True)
     cases["big_420_200x120"] = jpeg(picture(200, 120, 50), quality=75, subsampling=2)
     cases["progressive_24x24"] = jpeg(picture(24, 24, 51), quality=75, progressive=True)
+    cases["progressive_444_31x19"] = jpeg(picture(31, 19, 52), quality=85, progressive=True, subsampling=0)
+    cases["progressive_422_40x21"] = jpeg(picture(40, 21, 53), quality=60, progressive=True, subsampling=1, optimize=True)
+    cases["progressive_420_57x33"] = jpeg(picture(57, 33, 54), quality=35, progressive=True, subsampling=2, restart_marker_blocks=2)
+    cases["progressive_gray_17x29"] = jpeg(picture(17, 29, 55, gray=True), quality=90, progressive=True)
+    cases["progressive_q5_64x48"] = jpeg(picture(64, 48, 56), quality=5, progressive=True, subsampling=2)
     out = {}
     for name, data in cases.items():
         want = stb(data)
         assert want is not None, name
         out["file_" + name] = np.frombuffer(data, np.uint8)
-        if not name.startswith("progressive"):
-            out["rgba_" + name] = want
+        out["rgba_" + name] = want
         print(f"{name:22s} {len(data):6d} bytes -> {want.shape}")
     # PNG through the same decoder (tests/gltf_files.py writes them; the expected bytes come from stb_image too)
     import sys
@@ -94,6 +99,31 @@ def main():
         data = png_bytes(img)
         out[f"file_png{c}_13x10"] = np.frombuffer(data, np.uint8)
         out[f"rgba_png{c}_13x10"] = stb(data)
+    # every colour type x bit depth, plain and Adam7, with and without tRNS (tests/gltf_files.py: png_bytes_general)
+    from gltf_files import png_bytes_general
+    rng = np.random.default_rng(10)
+    for ctype, depths in ((0, (1, 2, 4, 8, 16)), (2, (8, 16)), (3, (1, 2, 4, 8)), (4, (8, 16)), (6, (8, 16))):
+        for depth in depths:
+            for interlace in (False, True):
+                c = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+                w, h = int(rng.integers(3, 20)), int(rng.integers(3, 14))
+                plte = trns = None
+                if ctype == 3:
+                    npal = min(1 << depth, int(rng.integers(2, 200)))
+                    plte = rng.integers(0, 256, npal * 3).astype(np.uint8)
+                    smp = rng.integers(0, npal, (h, w, 1))
+                    if interlace:
+                        trns = rng.integers(0, 256, max(1, npal // 2)).astype(np.uint8)
+                else:
+                    smp = rng.integers(0, 1 << depth, (h, w, c))
+                    if ctype in (0, 2) and not interlace:
+                        trns = b"".join(int(v).to_bytes(2, "big") for v in smp[h // 2, w // 2])
+                data = png_bytes_general(smp, depth, ctype, interlace, plte, trns)
+                name = f"pngx_c{ctype}_d{depth}_{'adam7' if interlace else 'plain'}_{w}x{h}"
+                want = stb(data)
+                assert want is not None, name
+                out["file_" + name] = np.frombuffer(data, np.uint8)
+                out["rgba_" + name] = want
     np.savez_compressed(os.path.join(HERE, "jpeg_cases.npz"), **out)
     print("wrote", os.path.join(HERE, "jpeg_cases.npz"), os.path.getsize(os.path.join(HERE, "jpeg_cases.npz")), "bytes")
 

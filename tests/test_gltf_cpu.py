@@ -334,19 +334,16 @@ def _stb_decode(data):
 
 
 def test_jpeg_decode_matches_committed_stb_image_bytes(tmp_path):
-    """Baseline JPEG textures (what Blender's glTF exporter writes by default): the product's decoder against the bytes
-    the reference's own vendored stb_image gives (tests/golden/jpeg_cases.npz, made by tests/golden/make_jpeg_golden.py
-    with Pillow as the encoder): every sampling layout stb has a filter for, grayscale, odd sizes down to 1x1, restart
-    intervals, Adobe RGB; bit-exact. The PNG decoder is checked against the same source."""
+    """JPEG textures (baseline, what Blender's glTF exporter writes by default, and — round 3 — progressive): the product's
+    decoder against the bytes the reference's own vendored stb_image gives (tests/golden/jpeg_cases.npz, made by
+    tests/golden/make_jpeg_golden.py with Pillow as the encoder): every sampling layout stb has a filter for, grayscale,
+    odd sizes down to 1x1, restart intervals, Adobe RGB, progressive scans with successive approximation; bit-exact. The
+    PNG decoder is checked against the same source: every colour type and bit depth, plain and Adam7, with tRNS."""
     Z = np.load(JPEG_CASES)
     names = [k[5:] for k in Z.files if k.startswith("file_")]
-    assert len(names) >= 28
+    assert len(names) >= 28 + 5 + 30 and sum(n.startswith("progressive") for n in names) >= 6
     for name in names:
         data = Z["file_" + name].tobytes()
-        if name.startswith("progressive"):
-            with pytest.raises(_lib.SrxError, match="progressive"):
-                gltf.decode_image(data)
-            continue
         got = gltf.decode_image(data)
         want = Z["rgba_" + name]
         assert got.shape == want.shape, name
@@ -393,7 +390,7 @@ def test_image_decoders_match_stb_image_built_from_the_reference():
     qualities than the committed ones, written here with Pillow when it is importable) decode identically."""
     Z = np.load(JPEG_CASES)
     for k in Z.files:
-        if k.startswith("file_") and not k.startswith("file_progressive"):
+        if k.startswith("file_"):
             assert np.array_equal(_stb_decode(Z[k].tobytes()), Z["rgba_" + k[5:]]), k
     PIL = pytest.importorskip("PIL.Image")
     import io
@@ -403,6 +400,6 @@ def test_image_decoders_match_stb_image_built_from_the_reference():
         img = np.clip(rng.normal(128, 60, (h, w, 3)) + np.linspace(-80, 80, w)[None, :, None], 0, 255).astype(np.uint8)
         b = io.BytesIO()
         PIL.fromarray(img if i % 5 else img[..., 0]).save(b, "JPEG", quality=int(rng.integers(5, 100)), subsampling=int(rng.integers(0, 3)),
-                                                          restart_marker_blocks=int(rng.integers(0, 4)), optimize=bool(i % 2))
+                                                          restart_marker_blocks=int(rng.integers(0, 4)), optimize=bool(i % 2), progressive=bool(i % 3 == 0))
         got, want = gltf.decode_image(b.getvalue()), _stb_decode(b.getvalue())
         assert np.array_equal(got, want), (i, w, h)

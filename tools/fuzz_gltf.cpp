@@ -15,6 +15,25 @@ int main(int argc, char** argv) {
     if (good.empty()) { printf("no input\n"); return 2; }
     std::mt19937 rng(12345);
     int ok = 0, bad = 0, packed = 0;
+    if (good.size() < 4 || memcmp(good.data(), "glTF", 4)) {
+        // an image file (PNG / JPEG): the decoders on their own (srx_image_decode), same mutations minus the JSON ones
+        std::vector<unsigned char> px;
+        for (int it = 0; it < iters; it++) {
+            std::vector<unsigned char> v = good;
+            const int kind = it == 0 ? -1 : it % 4;
+            if (kind == 0) v.resize(rng() % v.size());
+            else if (kind == 1) { int n = 1 + rng() % 8; for (int k = 0; k < n; k++) v[rng() % v.size()] ^= (unsigned char)(1u << (rng() % 8)); }
+            else if (kind == 2) { size_t p = rng() % v.size(); size_t n = rng() % 32; for (size_t k = 0; k < n && p + k < v.size(); k++) v[p + k] = (unsigned char)rng(); }
+            else if (kind == 3) { v[rng() % v.size()] = (unsigned char)rng(); }
+            uint32_t w = 0, h = 0;
+            if (srx_image_decode(v.data(), v.size(), &w, &h, nullptr, 0) == 0 && (uint64_t)w * h <= (1u << 22)) {
+                px.resize((size_t)w * h * 4);
+                if (srx_image_decode(v.data(), v.size(), &w, &h, px.data(), px.size()) == 0) ok++; else bad++;
+            } else bad++;
+        }
+        printf("decoded %d refused %d\n", ok, bad);
+        return 0;
+    }
     for (int it = 0; it < iters; it++) {
         std::vector<unsigned char> v = good;
         int kind = it % 6;

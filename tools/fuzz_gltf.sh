@@ -21,3 +21,14 @@ gltf_files.write_test_scene(sys.argv[2] + "/b.glb", seed=5, textures=False)
 EOP
 $W/fuzz $W/a.glb ${1:-3000}
 $W/fuzz $W/b.glb ${1:-3000}
+# the image decoders on their own: progressive and baseline JPEG, interlaced / 16-bit / palette PNG (files of tests/golden/jpeg_cases.npz)
+python3 - "$R" "$W" <<'EOP'
+import sys, numpy as np
+Z = np.load(sys.argv[1] + "/tests/golden/jpeg_cases.npz")
+want = ["progressive_420_57x33", "progressive_gray_17x29", "progressive_422_40x21", "restart_420_50x35"]
+want += [k[5:] for k in Z.files if k.startswith("file_pngx_") and ("adam7" in k or "_d16_" in k or "_c3_" in k)][:10]
+for i, name in enumerate(want):
+    open(f"{sys.argv[2]}/img{i}.bin", "wb").write(Z["file_" + name].tobytes())
+print(len(want))
+EOP
+for f in $W/img*.bin; do $W/fuzz $f ${1:-3000}; done
