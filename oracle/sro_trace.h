@@ -78,8 +78,8 @@ static inline int leaf_filter(const float* box6, uint32_t cone, const XYZ& o, co
     const float fx = std::max(x1, x2), fy = std::max(y1, y2), fz = std::max(z1, z2);
     const float smin = std::max(nz, std::max(ny, nx));
     const float smax = std::min(fz, std::min(fy, fx));
-    const float ex = std::max(-nx, fx) * (std::fabs(d.X) * c1), ey = std::max(-ny, fy) * (std::fabs(d.Y) * c1), ez = std::max(-nz, fz) * (std::fabs(d.Z) * c1);
-    const float pt = std::max(ez, std::max(ey, ex)) + floor_t;
+    const float ex = std::max(-nx, fx) * std::fabs(d.X), ey = std::max(-ny, fy) * std::fabs(d.Y), ez = std::max(-nz, fz) * std::fabs(d.Z);
+    const float pt = std::fmaf(c1, std::max(ez, std::max(ey, ex)), floor_t);
     if (!(smin - smax > pt + pt) && !(smax < -pt)) return 1;
     const float sc = 127.0f / std::sqrt(dd);
     const int qx = (int)std::nearbyint(d.X * sc), qy = (int)std::nearbyint(d.Y * sc), qz = (int)std::nearbyint(d.Z * sc);

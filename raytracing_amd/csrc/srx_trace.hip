@@ -125,19 +125,19 @@ __device__ __forceinline__ float x86_max(float a, float b) { return a > b ? a : 
 // z = fma(0, 1/d, -o/d), which is -o/d itself up to the sign of a zero (a zero result is "no hit" either way).
 //   Filter: a leaf is skipped (may_hit false) when BOTH hold: (1) the stored box's interval, widened by pt on both
 // ends, is empty or behind the ray, with pt = SRX_FILTER_PAD_REL x the largest coordinate distance from the ray's origin
-// to the box (max|t_plane| |d_axis|, in units of t: c1 = SRX_FILTER_PAD_REL max|1/d|; the caller passes cd = |d| c1) + floor_t, the absolute part
+// to the box (max|t_plane| |d_axis|, in units of t: c1 = SRX_FILTER_PAD_REL max|1/d|) + floor_t, the absolute part
 // (SRX_FILTER_PAD_ABS x (scene size + max|o|) max|1/d|; infinite for rays that are never filtered); (2) the ray keeps clear of the planes of
 // all the leaf's triangles, |a . dq| >= 127 h with the leaf's cone word (srx_device.h): near such a plane the
 // reference's triangle test divides by a det that is rounding noise and can accept far outside the padded box
 // (tests/test_leaf_filter_*.py). An inner child that the reference test accepts always passes (1)
 // and its cone word is 0 (a = 0, h = 0: (2) holds trivially).
-template <bool FAST>
-__device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, const f3 inv, const f3 fused, const f3 cd, const int dq,
-                                              const float floor_t, bool& may_hit) {
+template <bool FAST, bool SDQ>
+__device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, const f3 inv, const f3 fused, const f3 d, const float c1, const int dq,
+                                              const float floor_t, const float zero_key_limit, bool& valid, unsigned long long& valid_mask) {
     const float tx1 = __fmaf_rn(A.x, inv.x, fused.x), tx2 = __fmaf_rn(A.w, inv.x, fused.x);
     const float ty1 = __fmaf_rn(A.y, inv.y, fused.y), ty2 = __fmaf_rn(B.x, inv.y, fused.y);
     const float tz1 = __fmaf_rn(A.z, inv.z, fused.z), tz2 = __fmaf_rn(B.y, inv.z, fused.z);
-    const bool ext = (f2u(B.z) & SRX_LINK_EXT) != 0u;
+    const bool ext = f2u(B.z) >= (SRX_LINK_LEAF | SRX_LINK_EXT);   // only leaf children carry SRX_LINK_EXT (srx_scene.hip): one unsigned compare
     const float nx = hw_min(tx1, tx2), ny = hw_min(ty1, ty2), nz = hw_min(tz1, tz2);
     const float fx = hw_max(tx1, tx2), fy = hw_max(ty1, ty2), fz = hw_max(tz1, tz2);
     const float smin = hw_max3(nz, ny, nx), smax = hw_min3(fz, fy, fx);
@@ -146,12 +146,18 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, co
     const bool clear_of_planes = true;   // experiment builds only (unsound): what the guard costs
 #else
     const uint32_t cone = f2u(B.w);
-    const int sd = __builtin_amdgcn_sdot4((int)cone, dq, 0, false);
+    // v_dot4_i32_i8 with the constant 0 as its accumulator (the builtin becomes v_dot4c, which accumulates into its destination
+    // and needs a v_mov of 0 first)
+    int sd;
+    if (SDQ) asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(sd) : "v"(cone), "s"(dq));
+    else asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(sd) : "v"(cone), "v"(dq));
     const bool clear_of_planes = (uint32_t)abs(sd) >= (cone >> 24) * 127u;
 #endif
-    const float ex = hw_max_neg(nx, fx) * cd.x, ey = hw_max_neg(ny, fy) * cd.y, ez = hw_max_neg(nz, fz) * cd.z;   // cd = |d| c1 per axis
-    const float pt = hw_max3(ez, ey, ex) + floor_t;
-    may_hit = (!(smin - smax > pt + pt) && !(smax < -pt)) || !clear_of_planes;
+    // largest coordinate distance from the origin to the box (the |d| are operand modifiers), then c1 x that + the floor in one FMA
+    const float ex = hw_max_neg(nx, fx) * fabsf(d.x), ey = hw_max_neg(ny, fy) * fabsf(d.y), ez = hw_max_neg(nz, fz) * fabsf(d.z);
+    const float pt = __fmaf_rn(c1, hw_max3(ez, ey, ex), floor_t);
+    const bool not_empty = !(smin - smax > pt + pt), not_behind = !(smax < -pt);
+    const bool may_hit = (not_empty && not_behind) || !clear_of_planes;
     float tmin, tmax;
     if (FAST) {
         const float emin = hw_max3(hw_min(nz, fused.z), hw_min(ny, fused.y), hw_min(nx, fused.x));
@@ -173,18 +179,27 @@ __device__ __forceinline__ uint32_t node_test(const float4 A, const float4 B, co
         tmin = x86_max(tminz, x86_max(tminy, tminx));
         tmax = x86_min(tmaxz, x86_min(tmaxy, tmaxx));
     }
-    const bool hit = (tmax >= 0.0f) && (tmin < tmax);
-    return hit ? f2u(tmin) : 0u;
+    // The reference's result is hit ? tmin : 0, and a zero result (either sign) is "no hit"; the ordering key carries the
+    // lane id in its low 3 mantissa bits and a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:74-78, :86): both
+    // together are |tmin| > (lane == 0 ? the float with bits 7 : 0), a float compare (denormals are on; tmin is no NaN when
+    // tmin < tmax holds). A leaf the ray cannot hit is not pushed either. The wave's mask of valid lanes is put together
+    // from the masks of the single compares (scalar ANDs) instead of a ballot of the combined flag, which the compiler
+    // turns into a select and a second compare.
+    const bool in_front = tmax >= 0.0f, ordered = tmin < tmax, nonzero = fabsf(tmin) > zero_key_limit;
+    valid = in_front && ordered && nonzero && may_hit;
+    valid_mask = __builtin_amdgcn_ballot_w64(in_front) & __builtin_amdgcn_ballot_w64(ordered) & __builtin_amdgcn_ballot_w64(nonzero) &
+                 ((__builtin_amdgcn_ballot_w64(not_empty) & __builtin_amdgcn_ballot_w64(not_behind)) | __builtin_amdgcn_ballot_w64(!clear_of_planes));
+    return f2u(tmin);   // the reference's result where `valid` holds; not used elsewhere
 }
 
 // MODE 0: closest hit.  MODE 1: shadow, API form (writes lit[]).  MODE 2: shadow, renderer queue form.
 // MODE 3: MODE 2 for a scene with ONE sun: every ray of the launch has the same direction (SunLight::vectorTo returns the
-// stored vector whatever the point, Primitives.h:39-51), so 1/d, |d| c1, the guard's quantised direction and d itself are
+// stored vector whatever the point, Primitives.h:39-51), so 1/d, c1, the guard's quantised direction and d itself are
 // per-launch constants held in scalar registers instead of per-ray values in LDS and vector registers.
 // SPILL: the launch keeps a.lds_depth < sc.stack_depth entries per octet in LDS; the bottom half of an octet's LDS part
 // moves to the wave's overflow area in memory when a push might not fit, and comes back when the LDS part runs empty.
 template <int MODE, int K, bool SPILL>
-__global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArgs a) {
+__global__ __launch_bounds__(SRX_TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_trace(GScene sc, TraceArgs a) {
     // LDS: traversal stack [depth][octets of the block] of (tmin bits << 32 | link), then one 16-B best-hit record per octet
     extern __shared__ unsigned long long s_mem[];
     // one unused row below the stack, so that the entry under an octet's only entry can be read without a bounds test
@@ -196,7 +211,8 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     const int lane = threadIdx.x & 63;
     const int oct_shift = lane & ~7;
     const uint32_t sub16 = (uint32_t)sub << 4;
-    const uint32_t zero_key_limit = sub == 0 ? 7u : 0u;
+    const uint32_t sub8 = 256u + 8u * (uint32_t)sub;     // a lane's 8-B slot of a packet's third line
+    const float zero_key_limit = u2f(sub == 0 ? 7u : 0u);
     // XCD-aware block -> ray-range map: blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), so
     // XCD x works on the x-th contiguous eighth of the queue (queue order follows pixel / parent order).
     // Speed only; any placement gives the same results.
@@ -291,7 +307,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
     int dq = 0;
     // UNI: the launch's one direction and what derives from it, in scalar registers (the same arithmetic as the per-ray
     // set-up above, on the same numbers: d comes from the same GSun)
-    f3 u_d, u_cd;
+    f3 u_d;
     if (UNI) {
         const f3 ud(sc.suns[0].dir[0], sc.suns[0].dir[1], sc.suns[0].dir[2]);
         const f3 ui = f3(1.0f) / ud;
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         auto sgpr = [](float x) { return u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(x))); };
         u_d = f3(sgpr(ud.x), sgpr(ud.y), sgpr(ud.z));
         inv = f3(sgpr(ui.x), sgpr(ui.y), sgpr(ui.z));
-        u_cd = f3(sgpr(fabsf(ud.x) * uc1), sgpr(fabsf(ud.y) * uc1), sgpr(fabsf(ud.z) * uc1));
+        c1 = sgpr(uc1);
         dq = __builtin_amdgcn_readfirstlane((int)udq);
     }
     auto load_ray_j = [&](int j) {
@@ -367,7 +383,8 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
         // opposite order costs 4 %).
         __builtin_amdgcn_s_setprio(3);
         // pop until an entry survives the distance cull (Core.h:63-68)
-        uint32_t link = 0;
+        uint32_t link;   // read only where `go` holds
+        asm volatile("" : "=v"(link));   // no instruction: spares the v_mov of a 0 nobody reads
         bool go = false;
         if (MODE == 0) {
             // the top TWO entries in one LDS round trip (Core.h:63-68 pops until an entry survives the cull: a loop of
@@ -397,6 +414,10 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             // node (2 lines) and packet (3 lines) fetches are issued together, before the two kinds part ways;
             // the shift drops the leaf bit: byte offset = line * 128 + lane * 16, off one SGPR base
             const uint32_t off = (link << 7) | sub16;
+            // made before the loads go out (the empty asm pins it here): left to the compiler it is made in the leaf branch, in a
+            // register the loads above write, and the third load then waits for the first two
+            uint32_t off3 = (link << 7) + sub8;
+            asm volatile("" : "+v"(off3));
             const char* const rec = sc.geom + (size_t)off;
             const float4 A = *(const float4*)rec;
 #ifdef SRX_EXP_B3
@@ -410,23 +431,23 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
             __builtin_amdgcn_s_setprio(0);
             if (!leaf) {
                 n_nodes++;
-                bool may_hit;
-                const f3 cd = UNI ? u_cd : f3(fabsf(d.x) * c1, fabsf(d.y) * c1, fabsf(d.z) * c1);
-                const uint32_t rb = fast ? node_test<true>(A, B, inv, fused, cd, dq, floor_t, may_hit)
-                                         : node_test<false>(A, B, inv, fused, cd, dq, floor_t, may_hit);
-                // ordering key (Core.h:74-78): low 3 mantissa bits <- lane id. result==0 (either sign) is "no hit";
-                // a key that is itself +-0 is skipped by `if (num != 0)` (Core.h:86): both together are
-                // |result| > (lane == 0 ? 7 : 0)
-                const uint32_t kb = (rb & ~7u) | (uint32_t)sub;
-                // a leaf the ray cannot hit is not pushed
-                const bool valid = (rb & 0x7fffffffu) > zero_key_limit && may_hit;
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid);
+                bool valid;
+                unsigned long long bal;
+                const uint32_t rb = fast ? node_test<true, UNI>(A, B, inv, fused, d, c1, dq, floor_t, zero_key_limit, valid, bal)
+                                         : node_test<false, UNI>(A, B, inv, fused, d, c1, dq, floor_t, zero_key_limit, valid, bal);
                 const uint32_t vmask = (uint32_t)(bal >> oct_shift) & 0xFFu;
                 const int nvalid = __popc(vmask);
                 int rank;
                 if (MODE == 0) {
                     // total order of floats as unsigned ints (no NaN keys exist); invalid lanes sort last
-                    const uint32_t ord = valid ? (kb ^ ((uint32_t)((int32_t)kb >> 31) | 0x80000000u)) : 0xFFFFFFFFu;
+                    // kb = (rb & ~7) | lane id (the key, Core.h:74-78), ord = kb ^ ((kb >> 31, arithmetic) | 0x80000000): as three
+                    // instructions (bit-field insert, shift, one three-input bit operation: a ^ (b | c) is table 0x1e) where the
+                    // compiler makes four
+                    uint32_t kb, ok;
+                    const uint32_t sign = (uint32_t)((int32_t)rb >> 31);
+                    asm("v_bfi_b32 %0, 7, %1, %2" : "=v"(kb) : "v"(sub), "v"(rb));
+                    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x1e" : "=v"(ok) : "v"(kb), "v"(sign), "s"(0x80000000u));
+                    const uint32_t ord = valid ? ok : 0xFFFFFFFFu;
                     rank = octet_rank_u32(ord);
                 } else {
                     // Shadow casts only ask "is there a hit with 0 < t <= 9999": the answer does not depend on the
@@ -441,7 +462,7 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) void k_trace(GScene sc, TraceArg
                 // ---- leaf: one packet of 8 triangles per trip, one triangle per lane (Primitives.h:159-202).
                 // The rest of a multi-packet leaf goes back on top with distance -inf: it is never culled, exactly
                 // like the reference's inner `for` over the leaf's packets (Core.h:179).
-                const float2 C = *(const float2*)(rec + 256 - 8 * sub);   // third line: 8 x {e2.y, e2.z}, 8-B slots
+                const float2 C = *(const float2*)(sc.geom + (size_t)off3);   // third line: 8 x {e2.y, e2.z}, 8-B slots
                 const float2 r1 = *(const float2*)(ray_setup + 1);
                 const f3 o(r0.w, r1.x, r1.y);
                 if ((link & (SRX_LINK_MORE_MAX << SRX_LINK_MORE_SHIFT)) != 0u) {
