@@ -6,15 +6,20 @@ Usage: pmc_derive.py <pmc_raw.txt> <kernel_stats_single_stream.csv> <passes in t
 import csv, json, re, sys
 from collections import defaultdict
 
+def fold(name):
+    """k_trace<MODE, K, SPILL> -> k_trace<MODE>, and the one-sun shadow form (MODE 3) under the general form's name (MODE 2)."""
+    k = re.sub(r"<(\d), \d(?:, \w+)?>", r"<\1>", name.replace("void ", ""))
+    return "k_trace<2>" if k == "k_trace<3>" else k
+
 tot = defaultdict(float); disp = defaultdict(int)
 for line in open(sys.argv[1]):
     m = re.match(r"(.*?)\s+(\S+)\s+total\s+(\S+)\s+per_dispatch\s+\S+\s+dispatches\s+(\d+)", line)
     if m and not line.startswith("#"):
-        k = re.sub(r"<(\d), \d(?:, \w+)?>", r"<\1>", m.group(1).strip().replace("void ", ""))     # fold the K variants of a mode
+        k = fold(m.group(1).strip())     # fold the K variants of a mode
         tot[(k, m.group(2))] += float(m.group(3)); disp[(k, m.group(2))] += int(m.group(4))
 ms = defaultdict(float)
 for r in csv.DictReader(open(sys.argv[2])):
-    k = re.sub(r"<(\d), \d(?:, \w+)?>", r"<\1>", r["Name"].split("(")[0].replace("void ", ""))
+    k = fold(r["Name"].split("(")[0])
     ms[k] += float(r["TotalDurationNs"]) / 1e6 / int(sys.argv[3])
 bench = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
 out = {}
