@@ -462,8 +462,9 @@ def main():
             },
             "units_busy": ({k: prof[k] for k in ("valu_busy", "ta_busy", "td_busy", "td_tc_stall_of_busy", "waves_per_simd", "wait_any",
                                                  "l1_hit", "l2_hit") if k in prof} if prof else None),
-            "limiter": "latency of a trip (pop -> dependent gather -> ~150 VALU + 55 SALU -> push) x 13.8 trips per ray at 8 waves per SIMD; "
-                       "no throughput unit is saturated (DESIGN.md section 6)",
+            "limiter": (f"latency of a trip (pop -> dependent gather -> ~148 VALU + 36 SALU for a wave-trip with both kinds of octet -> push) "
+                        f"x {(agg['nodes'] + agg['packets']) / max(1.0, rays):.1f} trips per ray at 8 waves per SIMD; no throughput unit is saturated "
+                        "(DESIGN.md section 6, profiles/r03_trace_isa.md)"),
             "concurrency": ("shadow kernels run on a second stream beside this kernel: avg_launch_ms includes the time they share the chip")
                            if os.environ.get("SRX_SHADOW_STREAM", "1") != "0" else "one stream",
             # the same with the bytes a test actually uses of a record (264 of the 288-B node, 324 of the

@@ -94,6 +94,9 @@ struct GCamera {
     int res_x, res_y, subdiv;
 };
 
+// A parked bounce loop (ShadeArgs::cont_out): the ray's slot in the segment and the loop's state (Core.h:498-591: slots
+// used, attempts made, the throughput carried into a retry, quirk Q8) with the ray's random stream.
+struct GCont { uint32_t idx, i, ri; float tr, tg, tb; uint64_t s; };
 struct ShadeArgs {
     const GRay* rays;              // queue segment being shaded
     const GHit* hits;              // hit record of each ray of the segment
@@ -107,7 +110,23 @@ struct ShadeArgs {
     float* sample3;                // per-pixel sample sums (float atomics)
     unsigned long long* counters;  // [4] hits, [5] texels, [6] pdf lookups, [7] children (of slot 0)
     uint32_t counter_slot_mask, counter_slot_stride;   // as in TraceArgs
+    // Rounds (optional): a wave whose bounce loop is down to `spill_below` busy lanes or fewer parks them in `cont_out`
+    // (one GCont each) and leaves; a later launch with `cont_in` set takes min(*n_ptr, n) RECORDS, 64 to a wave again, and
+    // goes on where they stopped (no emissive term, no shadow rays, no hit / texel counts: the first round made those).
+    const GCont* cont_in;
+    GCont* cont_out;
+    uint32_t* cont_count;          // device counter of cont_out
+    uint32_t cont_capacity;        // slots of cont_out (the launcher sizes it so that it cannot overflow)
+    int spill_below;
+    int spill_after;               // ... and not before the wave has made this many trips
+    // Optional: the launch's units are the entries of this list of slots of `rays` / `hits` (srx_launch_hitlist: the rays of
+    // a batch that hit something, so that an open scene's misses do not leave lanes idle); n / n_ptr then count entries.
+    const uint32_t* slot_list;
 };
+
+// Writes the slots (0 .. min(*n_ptr, n) - 1) of the rays that hit something to `list` and their number to *count (one
+// atomic per block of 1 024 rays; order: by block as the blocks get their turn, ascending within a block).
+extern "C" hipError_t srx_launch_hitlist(const GHit* hits, uint32_t n, const uint32_t* n_ptr, uint32_t* list, uint32_t* count, hipStream_t stream);
 
 extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hipStream_t stream);
 // Rows of a pass: local row j of this caller is image row

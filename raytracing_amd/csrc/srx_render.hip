@@ -61,8 +61,27 @@ struct srx_renderer {
     uint64_t sample_pixels = 0;
     bool sample_dirty = false;        // a call ended half way: its sums are still in sample3
     hipStream_t stream = nullptr;
-    DeviceCounts* h_counts = nullptr; // pinned
+    DeviceCounts* h_counts = nullptr; // pinned: [0] a batch's counts, [1].shadow_count the shadow count after the first round
+    hipEvent_t round1_done = nullptr;
+    bool shadow_early = false;        // launch_batch has launched the batch's shadow kernel itself (beside the second round)
     bool timing = false;
+    // Rounds of the shade kernel (generations with a fan-out of 2 or more): the bounce loop of a ray runs until its slots are
+    // used, attempts that are rejected do not count, and a wave runs as long as its slowest lane; a wave down to `spill_below`
+    // busy lanes parks them (GCont) and the next round packs the parked loops of the whole batch 64 to a wave again.
+    int shade_rounds = 2;             // SRX_SHADE_ROUNDS=1: one launch per batch, every wave to its end (3: park a second time)
+    int spill_below = 16;
+    int rounds_min_fan = 2;           // generations with at least this fan-out are shaded in rounds
+    int park_pct = 100, park_add = 0; // a wave parks nothing before it has made bounce_count x park_pct / 100 + park_add trips (measured: 100 / 125 / 150 / 200 %)
+    GCont* cont[2] = {nullptr, nullptr};
+    uint64_t cont_cap[2] = {0, 0};
+    uint32_t* d_cont_count = nullptr; // two counters, SRX_COUNT_PAD dwords apart (a third: the hit list's)
+    // Hit list: in an open scene many rays of the later generations leave the scene, and their lanes sit idle all through
+    // the shade kernel. A generation whose batches hit less than `list_below` of the time (what the last batch of that
+    // generation did: shadow rays / rays, known to the host anyway) is shaded over the list of its hits instead.
+    float hit_ratio[32];
+    float list_below = 0.8f;          // SRX_SHADE_HITLIST=0: never; =1: always (tests)
+    uint32_t* hit_list = nullptr;
+    uint64_t hit_list_cap = 0;
     // per-call accumulators
     uint64_t top = 0;
     srx_counters acc;
@@ -98,6 +117,14 @@ extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_
         else chk(hipStreamCreateWithFlags(&r->shadow_stream, hipStreamNonBlocking));
     }
     if (const char* e3 = getenv("SRX_CHAIN")) r->chain = atoi(e3) != 0;                    // experiments / tests: 0 = a host round trip per generation
+    if (const char* e4 = getenv("SRX_SHADE_ROUNDS")) r->shade_rounds = std::max(1, std::min(3, atoi(e4)));
+    if (const char* e5 = getenv("SRX_SHADE_SPILL_BELOW")) r->spill_below = std::max(1, std::min(63, atoi(e5)));
+    if (const char* e6 = getenv("SRX_SHADE_ROUNDS_MIN_FAN")) r->rounds_min_fan = std::max(2, atoi(e6));
+    if (const char* e7 = getenv("SRX_SHADE_PARK_PCT")) r->park_pct = std::max(100, atoi(e7));
+    if (const char* e8 = getenv("SRX_SHADE_PARK_ADD")) r->park_add = std::max(0, atoi(e8));
+    chk(hipMalloc((void**)&r->d_cont_count, 3 * SRX_COUNT_PAD * sizeof(uint32_t)));
+    for (int i = 0; i < 32; i++) r->hit_ratio[i] = 1.0f;
+    if (const char* e9 = getenv("SRX_SHADE_HITLIST")) { const float v = (float)atof(e9); r->list_below = v >= 1.0f ? 2.0f : v; }
     for (int i = 0; i < 2; i++) {
         chk(hipMalloc((void**)&r->shadow_q[i], r->shadow_capacity * sizeof(GShadow)));
         chk(hipEventCreateWithFlags(&r->shadow_done[i], hipEventDisableTiming));
@@ -108,7 +135,8 @@ extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_
     chk(hipHostMalloc((void**)&r->h_ring, SRX_RING * sizeof(DeviceCounts)));
     chk(hipMalloc((void**)&r->d_counts, 3 * sizeof(DeviceCounts)));
     chk(hipMalloc((void**)&r->d_counters, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long)));
-    chk(hipHostMalloc((void**)&r->h_counts, sizeof(DeviceCounts)));
+    chk(hipHostMalloc((void**)&r->h_counts, 2 * sizeof(DeviceCounts)));
+    chk(hipEventCreateWithFlags(&r->round1_done, hipEventDisableTiming));
     if (e != hipSuccess) {
         srx_set_error(std::string("srx_renderer_create: ") + hipGetErrorString(e));
         srx_renderer_destroy(r);
@@ -133,7 +161,9 @@ extern "C" void srx_renderer_destroy(srx_renderer* r) {
     if (r->h_ring) (void)hipHostFree(r->h_ring);
     if (r->shadow_stream) (void)hipStreamDestroy(r->shadow_stream);
     (void)hipFree(r->d_counts); (void)hipFree(r->d_counters); (void)hipFree(r->sample3);
+    (void)hipFree(r->cont[0]); (void)hipFree(r->cont[1]); (void)hipFree(r->d_cont_count); (void)hipFree(r->hit_list);
     if (r->h_counts) (void)hipHostFree(r->h_counts);
+    if (r->round1_done) (void)hipEventDestroy(r->round1_done);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -203,6 +233,29 @@ int join_shadows(srx_renderer* r) {
     return 0;
 }
 
+// The shadow rays of a batch whose number the host has: on the second stream, beside whatever the main stream does next.
+// The shade launch that filled queue q is over (the host has waited for it). Lit rays add their contribution to the sample buffer.
+int launch_shadow_counted(srx_renderer* r, int q, uint64_t n_shadow) {
+    if (!n_shadow) return 0;
+    const GScene& g = r->scene->g;
+    TraceArgs sh;
+    std::memset(&sh, 0, sizeof(sh));
+    sh.org = &r->shadow_q[q][0].ox; sh.org_stride = sizeof(GShadow) / 4;
+    sh.n = (uint32_t)n_shadow;
+    sh.shadow_q = r->shadow_q[q]; sh.sample3 = r->sample3;
+    sh.counters = r->d_counters + CTR_SNODES; sh.counter_slot_mask = CTR_SLOTS - 1; sh.counter_slot_stride = CTR_COUNT;
+    hipStream_t ss = r->overlap_shadow ? r->shadow_stream : r->stream;
+    size_t ts;
+    if (t_begin(r, T_SHADOW, ss, &ts)) return 1;
+    SRX_HIP(srx_launch_trace(2, g, sh, ss));
+    if (t_end(r, ts, ss)) return 1;
+    SRX_HIP(hipEventRecord(r->shadow_done[q], ss));
+    r->shadow_busy[q] = true;
+    r->shadow_flip ^= 1;
+    r->acc.shadow_launches++;
+    return 0;
+}
+
 // One batch of rays through the closest-hit kernel, the shade kernel and (on the second stream) the shadow kernel.
 // n_ptr (device, optional): the batch holds min(*n_ptr, n) rays, n only sizes the grids. The children go to `out`, their
 // number and the number of shadow rays to `dc` (device). q = the shadow queue the shade kernel fills.
@@ -227,10 +280,72 @@ int launch_batch(srx_renderer* r, int gen, const GRay* in, uint32_t n, const uin
     s.out_rays = out; s.out_count = &dc->out_count;
     s.shadow_q = r->shadow_q[q]; s.shadow_count = &dc->shadow_count;
     s.sample3 = r->sample3; s.counters = r->d_counters; s.counter_slot_mask = CTR_SLOTS - 1; s.counter_slot_stride = CTR_COUNT;
+    // rounds: for the batches whose size the host knows (fan-out of 2 or more: the synchronous form)
+    const int rounds = (!n_ptr && gen < g.max_generations && g.bounce_count[gen] >= r->rounds_min_fan) ? r->shade_rounds : 1;
+    uint64_t need[2] = {0, 0};
+    if (rounds > 1) {
+        need[0] = ((uint64_t)n + 63) / 64 * (uint64_t)r->spill_below;          // a wave parks spill_below lanes at most
+        need[1] = (need[0] + 63) / 64 * (uint64_t)r->spill_below;
+        for (int k = 0; k < rounds - 1; k++) {
+            if (r->cont_cap[k] >= need[k]) continue;
+            SRX_HIP(hipStreamSynchronize(r->stream));                             // nothing enqueued may still use the old array
+            if (r->cont[k]) { SRX_HIP(hipFree(r->cont[k])); r->cont[k] = nullptr; r->cont_cap[k] = 0; }
+            const uint64_t cap = need[k] + need[k] / 4 + 1024;                    // batches of a generation differ a little from pass to pass: room to spare, so that the array is not made again every time one is a few rays larger
+            SRX_HIP(hipMalloc((void**)&r->cont[k], cap * sizeof(GCont)));
+            r->cont_cap[k] = cap;
+        }
+        SRX_HIP(hipMemsetAsync(r->d_cont_count, 0, 2 * SRX_COUNT_PAD * sizeof(uint32_t), r->stream));
+    }
+    // the hit list, for a generation whose rays mostly miss (sun-less scenes have no shadow count to tell by: never)
+    const bool listed = g.n_suns > 0 && gen < 32 && r->hit_ratio[gen] < r->list_below;
+    if (listed) {
+        if (r->hit_list_cap < n) {
+            SRX_HIP(hipStreamSynchronize(r->stream));
+            if (r->hit_list) { SRX_HIP(hipFree(r->hit_list)); r->hit_list = nullptr; r->hit_list_cap = 0; }
+            const uint64_t cap = (uint64_t)n + n / 4 + 1024;
+            SRX_HIP(hipMalloc((void**)&r->hit_list, cap * sizeof(uint32_t)));
+            r->hit_list_cap = cap;
+        }
+        uint32_t* const lc = r->d_cont_count + 2 * SRX_COUNT_PAD;
+        SRX_HIP(hipMemsetAsync(lc, 0, sizeof(uint32_t), r->stream));
+        s.slot_list = r->hit_list; s.n_ptr = lc;
+    }
     if (t_begin(r, T_SHADE, r->stream, &ts)) return 1;
-    SRX_HIP(srx_launch_shade(g, s, r->stream));
+    if (listed) SRX_HIP(srx_launch_hitlist(r->hits, n, n_ptr, r->hit_list, r->d_cont_count + 2 * SRX_COUNT_PAD, r->stream));
+    for (int k = 0; k < rounds; k++) {
+        ShadeArgs sk = s;
+        if (k > 0) { sk.cont_in = r->cont[k - 1]; sk.n = (uint32_t)need[k - 1]; sk.n_ptr = r->d_cont_count + (size_t)(k - 1) * SRX_COUNT_PAD; }
+        if (k + 1 < rounds) {
+            sk.cont_out = r->cont[k]; sk.cont_count = r->d_cont_count + (size_t)k * SRX_COUNT_PAD; sk.cont_capacity = (uint32_t)need[k];
+            sk.spill_below = r->spill_below;
+            sk.spill_after = std::max(1, g.bounce_count[gen]) * r->park_pct / 100 + r->park_add;
+        }
+        SRX_HIP(srx_launch_shade(g, sk, r->stream));
+        r->acc.shade_launches++;
+        // every shadow ray of the batch comes from the first round (a parked loop has queued its ray's already): with two
+        // streams their kernel starts as soon as that round is over, beside the later rounds, whose few waves with the longest loops leave most of the chip idle
+        if (k == 0 && rounds > 1 && !shadow_count_on_device && g.n_suns && r->overlap_shadow) {
+            SRX_HIP(hipMemcpyAsync(&r->h_counts[1].shadow_count, &dc->shadow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+            SRX_HIP(hipEventRecord(r->round1_done, r->stream));
+            r->shadow_early = true;
+        }
+    }
     if (t_end(r, ts, r->stream)) return 1;
-    r->acc.trace_launches++; r->acc.shade_launches++;
+    if (r->shadow_early) {
+        SRX_HIP(hipEventSynchronize(r->round1_done));
+        const uint64_t n_shadow = r->h_counts[1].shadow_count;
+        if (n_shadow > (uint64_t)n * g.n_suns) SRX_FAIL("srx: internal error, shadow count exceeds the queue");
+        if (launch_shadow_counted(r, q, n_shadow)) return 1;
+    }
+    r->acc.trace_launches++;
+    static const bool rounds_log = getenv("SRX_ROUNDS_LOG") != nullptr;
+    if (rounds_log && rounds > 1) {
+        uint32_t c[2] = {0, 0};
+        SRX_HIP(hipStreamSynchronize(r->stream));
+        SRX_HIP(hipMemcpy(&c[0], r->d_cont_count, 4, hipMemcpyDeviceToHost));
+        SRX_HIP(hipMemcpy(&c[1], r->d_cont_count + SRX_COUNT_PAD, 4, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "srx rounds gen %d: %u rays, parked %u then %u\n", gen, n, c[0], c[1]);
+    }
     if (!shadow_count_on_device) return 0;          // the caller launches the shadow kernel once it has the count
     if (g.n_suns) {
         // shadow rays of this batch, counted on the device: grid for the most there can be
@@ -315,6 +430,8 @@ int process_chain(srx_renderer* r, int gen, uint64_t begin, uint64_t n) {
     for (int k = 0; k < used; k++) {
         const uint64_t c = r->h_ring[k].out_count, sh = r->h_ring[k].shadow_count;
         if (c > n || sh > n * g.n_suns) SRX_FAIL("srx: internal error, a chained generation grew");
+        const uint64_t held = k == 0 ? n : (uint64_t)r->h_ring[k - 1].out_count;      // rays of link k
+        if (g.n_suns && held && gen + k < 32) r->hit_ratio[gen + k] = (float)((double)sh / ((double)held * g.n_suns));
         if (k + 1 < used) rays += c;
         else if (c != 0 && gen + k < g.max_generations) SRX_FAIL("srx: internal error, a chain ended with rays left");
         r->acc.shadows_cast += sh;
@@ -360,28 +477,14 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         const uint64_t n_children = r->h_counts->out_count, n_shadow = r->h_counts->shadow_count;
         if (n_children > n * fan || r->top + n_children > r->capacity) SRX_FAIL("srx: internal error, child count exceeds the reserved slots");
         if (n_shadow > n * g.n_suns) SRX_FAIL("srx: internal error, shadow count exceeds the queue");
+        if (g.n_suns && gen < 32) r->hit_ratio[gen] = (float)((double)n_shadow / ((double)n * g.n_suns));
 
         // ---- shadow rays of this batch, on the second stream: the kernel runs next to the closest-hit kernel of the
         // next generation (launched below on the main stream). The shade kernel that filled the queue is over (host
         // synchronised above). Lit rays add their contribution to the sample buffer. (For these large batches, launching
         // it before the synchronisation with the count read on the device measured slower: 1250 against 1263 Mrays/s.)
-        if (n_shadow) {
-            TraceArgs sh;
-            std::memset(&sh, 0, sizeof(sh));
-            sh.org = &r->shadow_q[q][0].ox; sh.org_stride = sizeof(GShadow) / 4;
-            sh.n = (uint32_t)n_shadow;
-            sh.shadow_q = r->shadow_q[q]; sh.sample3 = r->sample3;
-            sh.counters = r->d_counters + CTR_SNODES; sh.counter_slot_mask = CTR_SLOTS - 1; sh.counter_slot_stride = CTR_COUNT;
-            hipStream_t ss = r->overlap_shadow ? r->shadow_stream : r->stream;
-            size_t ts;
-            if (t_begin(r, T_SHADOW, ss, &ts)) return 1;
-            SRX_HIP(srx_launch_trace(2, g, sh, ss));
-            if (t_end(r, ts, ss)) return 1;
-            SRX_HIP(hipEventRecord(r->shadow_done[q], ss));
-            r->shadow_busy[q] = true;
-            r->shadow_flip ^= 1;
-            r->acc.shadow_launches++;
-        }
+        if (!r->shadow_early && launch_shadow_counted(r, q, n_shadow)) return 1;
+        r->shadow_early = false;
         r->acc.rays_processed += n;
         r->acc.shadows_cast += n_shadow;
         // ---- next generation, depth first
@@ -400,6 +503,7 @@ int begin_call(srx_renderer* r) {
     for (int i = 0; i < 2; i++) if (retire_shadow(r, i, true)) return 1;   // left over from a call that failed half way
     std::memset(&r->acc, 0, sizeof(r->acc));
     r->timed.clear(); r->ev_used = 0;
+    r->shadow_early = false;
     // everything a failed call may have left running is over now (both shadow queues retired above, and every error path
     // of this file comes after a synchronisation of the main stream or leaves nothing enqueued on it that uses sample3)
     SRX_HIP(hipStreamSynchronize(r->stream));

@@ -168,26 +168,29 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #ifndef SRX_SHADE_WAVES
 #define SRX_SHADE_WAVES 4
 #endif
-#ifdef SRX_SHADE_MIN_WAVES   // experiments: cap the registers for this many waves per SIMD
-#define SRX_SHADE_BOUNDS __launch_bounds__(64 * SRX_SHADE_WAVES, SRX_SHADE_MIN_WAVES)
-#else
-#define SRX_SHADE_BOUNDS __launch_bounds__(64 * SRX_SHADE_WAVES)
-#endif
-__global__ SRX_SHADE_BOUNDS void k_shade(GScene sc, ShadeArgs a) {
+// WAVES: waves per block. The block shares the two queue reservations (shadow rays at the top, the last children at the
+// end), so its waves leave together, after the slowest of them; srx_launch_shade picks WAVES per generation.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_shade(GScene sc, ShadeArgs a) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool live = idx < (a.n_ptr ? min(*a.n_ptr, a.n) : a.n);
-    __shared__ GRay s_stage[SRX_SHADE_WAVES][SRX_STAGE];          // per-wave staging of surviving children (36 KB per block: 4 blocks = 16 waves per CU, what 116 VGPRs allow)
-    __shared__ uint32_t s_wave_count[SRX_SHADE_WAVES];
-    __shared__ uint32_t s_base[2];
+    __shared__ GRay s_stage[WAVES][SRX_STAGE];          // per-wave staging of surviving children (36 KB per block: 4 blocks = 16 waves per CU, what 116 VGPRs allow)
+    __shared__ uint32_t s_wave_count[WAVES], s_wave_parked[WAVES];
+    __shared__ uint32_t s_base[3];
     GRay* const stage = s_stage[threadIdx.x >> 6];
     uint32_t staged = 0;                      // wave-uniform
 
     GRay ray;
     GHit hit;
     hit.material = 0xFFFFFFFFu;
-    if (live) { ray = a.rays[idx]; hit = a.hits[idx]; }
+    const bool resumed = a.cont_in != nullptr;        // a later round: the launch's units are parked loops, not rays
+    GCont rec;
+    uint32_t slot = idx;
+    if (live && resumed) { rec = a.cont_in[idx]; slot = rec.idx; }
+    else if (live && a.slot_list) slot = a.slot_list[idx];
+    if (live) { ray = a.rays[slot]; hit = a.hits[slot]; }
     const bool is_hit = live && hit.material != 0xFFFFFFFFu;
 
     uint32_t n_texels = 0, n_pdf = 0, n_children = 0;
@@ -239,7 +242,7 @@ __global__ SRX_SHADE_BOUNDS void k_shade(GScene sc, ShadeArgs a) {
 
         // emissive term (Core.h:426): contribution = throughput * emissive
         const f3 e = thr * m.emissive;
-        if (e.x != 0.0f || e.y != 0.0f || e.z != 0.0f) {
+        if (!resumed && (e.x != 0.0f || e.y != 0.0f || e.z != 0.0f)) {
             float* dst = a.sample3 + 3 * (size_t)ray.pixel;
             atomicAdd(dst, e.x); atomicAdd(dst + 1, e.y); atomicAdd(dst + 2, e.z);
         }
@@ -254,11 +257,12 @@ __global__ SRX_SHADE_BOUNDS void k_shade(GScene sc, ShadeArgs a) {
     // on one hot word per wave would serialise the chip (~88 of them per microsecond, chip-wide).
     const int wave = threadIdx.x >> 6;
     const unsigned long long hit_bal = __ballot(is_hit);
+    if (!resumed) {                                   // (uniform over the launch)
     if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(hit_bal);
     __syncthreads();
     uint32_t hit_rank = (uint32_t)__popcll(hit_bal & lt_mask), block_hits = 0;
 #pragma unroll
-    for (int wv = 0; wv < SRX_SHADE_WAVES; wv++) {
+    for (int wv = 0; wv < WAVES; wv++) {
         const uint32_t c = s_wave_count[wv];
         if (wv < wave) hit_rank += c;
         block_hits += c;
@@ -279,6 +283,7 @@ __global__ SRX_SHADE_BOUNDS void k_shade(GScene sc, ShadeArgs a) {
             a.shadow_q[s_base[0] + hit_rank * sc.n_suns + s] = q;
         }
     }
+    }
 
     if (is_hit) {
         active = !(a.generation >= sc.max_generations);                // Core.h:473
@@ -289,6 +294,11 @@ __global__ SRX_SHADE_BOUNDS void k_shade(GScene sc, ShadeArgs a) {
     // ---- bounce loop (Core.h:498-591): every lane makes one attempt per trip; survivors are appended
     int i = 0, ri = 0;
     f3 throughput(1, 1, 1);
+    if (resumed && is_hit) {
+        i = (int)rec.i; ri = (int)rec.ri; throughput = f3(rec.tr, rec.tg, rec.tb); g.s = rec.s;
+        n_texels = 0;                                 // counted by the first round
+    }
+    int trips = 0;
     while (__any(active)) {
         bool emit = false;
         GRay child;
@@ -388,29 +398,43 @@ __global__ SRX_SHADE_BOUNDS void k_shade(GScene sc, ShadeArgs a) {
                 staged = 0;
             }
         }
+        // rounds: once every lane has had the trips a ray with few rejections needs (spill_after), a wave that is down to a few
+        // busy lanes parks them and leaves (the next round packs the parked loops of the whole launch 64 to a wave)
+        trips++;
+        if (a.cont_out && trips >= a.spill_after && __popcll(__ballot(active)) <= a.spill_below) break;
     }
-    // what is left is flushed with one reservation per block
+    // what is left is flushed with one reservation per block, and so are the parked loops
+    const unsigned long long parked_bal = __ballot(active);
     __syncthreads();
-    if (lane == 0) s_wave_count[wave] = staged;
+    if (lane == 0) { s_wave_count[wave] = staged; s_wave_parked[wave] = (uint32_t)__popcll(parked_bal); }
     __syncthreads();
     {
-        uint32_t before = 0, total = 0;
+        uint32_t before = 0, total = 0, p_before = 0, p_total = 0;
 #pragma unroll
-        for (int wv = 0; wv < SRX_SHADE_WAVES; wv++) {
-            const uint32_t c = s_wave_count[wv];
-            if (wv < wave) before += c;
-            total += c;
+        for (int wv = 0; wv < WAVES; wv++) {
+            const uint32_t c = s_wave_count[wv], pc = s_wave_parked[wv];
+            if (wv < wave) { before += c; p_before += pc; }
+            total += c; p_total += pc;
         }
         if (threadIdx.x == 0 && total) s_base[1] = atomicAdd(a.out_count, total);
+        if (threadIdx.x == 0 && p_total) s_base[2] = atomicAdd(a.cont_count, p_total);
         __syncthreads();
         if (total) {
             const uint32_t base = s_base[1] + before;
             for (uint32_t k = lane; k < staged; k += 64) a.out_rays[base + k] = stage[k];
         }
+        if (active) {                                 // only with a.cont_out: without it the loop runs until no lane is active
+            const uint32_t at = s_base[2] + p_before + (uint32_t)__popcll(parked_bal & lt_mask);
+            if (at < a.cont_capacity) {
+                GCont c;
+                c.idx = slot; c.i = (uint32_t)i; c.ri = (uint32_t)ri; c.tr = throughput.x; c.tg = throughput.y; c.tb = throughput.z; c.s = g.s;
+                a.cont_out[at] = c;
+            }
+        }
     }
 
     // ---- counters: one atomic per wave and counter
-    const uint32_t w_hits = (uint32_t)__popcll(__ballot(is_hit));
+    const uint32_t w_hits = resumed ? 0u : (uint32_t)__popcll(__ballot(is_hit));
     const uint32_t w_tex = wave_sum_u32(n_texels), w_pdf = wave_sum_u32(n_pdf), w_child = wave_sum_u32(n_children);
     if (lane == 0 && a.counters) {
         unsigned long long* c = a.counters + (size_t)(blockIdx.x & a.counter_slot_mask) * a.counter_slot_stride;
@@ -633,10 +657,62 @@ __global__ __launch_bounds__(256) void k_accumulate(int res_x, int x0, int w, GR
   }
 }
 
+// ---------------------------------------------------------------- the rays of a batch that hit something
+__global__ __launch_bounds__(256) void k_hitlist(const GHit* hits, uint32_t n, const uint32_t* n_ptr, uint32_t* list, uint32_t* count) {
+    __shared__ uint32_t s_cnt[4][4];
+    __shared__ uint32_t s_base;
+    const uint32_t n_live = n_ptr ? min(*n_ptr, n) : n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t first = blockIdx.x * 1024u;
+    if (first >= n_live) return;
+    bool h[4];
+    unsigned long long bal[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const uint32_t r = first + (uint32_t)t * 256u + threadIdx.x;
+        h[t] = r < n_live && hits[r].material != 0xFFFFFFFFu;
+        bal[t] = __ballot(h[t]);
+        if (lane == 0) s_cnt[t][wave] = (uint32_t)__popcll(bal[t]);
+    }
+    __syncthreads();
+    uint32_t before[4], total = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int wv = 0; wv < 4; wv++) {
+            if (wv == wave) before[t] = total;
+            total += s_cnt[t][wv];
+        }
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(count, total) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        if (h[t]) list[s_base + before[t] + (uint32_t)__popcll(bal[t] & lt_mask)] = first + (uint32_t)t * 256u + threadIdx.x;
+}
+
 // ---------------------------------------------------------------- launchers
+extern "C" hipError_t srx_launch_hitlist(const GHit* hits, uint32_t n, const uint32_t* n_ptr, uint32_t* list, uint32_t* count, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hitlist, dim3((n + 1023u) / 1024u), dim3(256), 0, stream, hits, n, n_ptr, list, count);
+    return hipGetLastError();
+}
 extern "C" hipError_t srx_launch_shade(const GScene& sc, const ShadeArgs& a, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_shade, dim3((a.n + 64 * SRX_SHADE_WAVES - 1) / (64 * SRX_SHADE_WAVES)), dim3(64 * SRX_SHADE_WAVES), 0, stream, sc, a);
+    // waves per block by the generation's fan-out (experiments: SRX_SHADE_WAVES_BY_FANOUT="w32,w8,w2,w1")
+    static int by_fanout[4] = {SRX_SHADE_WAVES, SRX_SHADE_WAVES, SRX_SHADE_WAVES, SRX_SHADE_WAVES};
+    static const bool parsed = [] {
+        if (const char* e = getenv("SRX_SHADE_WAVES_BY_FANOUT")) (void)sscanf(e, "%d%*c%d%*c%d%*c%d", &by_fanout[0], &by_fanout[1], &by_fanout[2], &by_fanout[3]);
+        return true;
+    }();
+    (void)parsed;
+    const int fan = sc.bounce_count[a.generation < 32 ? a.generation : 31];
+    const int waves = by_fanout[fan >= 32 ? 0 : (fan >= 8 ? 1 : (fan >= 2 ? 2 : 3))];
+    const unsigned threads = 64u * (unsigned)(waves == 1 ? 1 : (waves == 2 ? 2 : 4));
+    const dim3 grid((a.n + threads - 1) / threads);
+    if (threads == 64) hipLaunchKernelGGL(k_shade<1>, grid, dim3(threads), 0, stream, sc, a);
+    else if (threads == 128) hipLaunchKernelGGL(k_shade<2>, grid, dim3(threads), 0, stream, sc, a);
+    else hipLaunchKernelGGL(k_shade<4>, grid, dim3(threads), 0, stream, sc, a);
     return hipGetLastError();
 }
 extern "C" hipError_t srx_launch_raygen(const GCamera& c, int x0, int w, GRows rows_map, int j0, int rows, uint32_t pass_index,

@@ -296,6 +296,50 @@ def test_chains_back_to_back(tables, monkeypatch, mcm, cap):
     assert np.allclose(a1[:, :3], a0[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
 
 
+@pytest.mark.parametrize("scene", ["atrium", "instanced"])
+def test_shade_rounds_equal_one_launch(tables, monkeypatch, scene):
+    """Rounds of the shade kernel (csrc/srx_render.hip launch_batch, csrc/srx_shade.hip: a wave whose bounce loop is down to a
+    few busy lanes parks them as GCont records, a second launch packs the parked loops of the batch 64 to a wave and goes on
+    where they stopped) against SRX_SHADE_ROUNDS=1 (every wave runs until its slowest ray is done, Core.h:498-591 as one
+    loop). A parked loop resumes with its slots, attempts, carried throughput (quirk Q8) and random stream: the same rays, the same
+    children and shadow rays, the same hits, texel fetches and PDF lookups, the same image. Also with three rounds and
+    with thresholds that park nearly everything / nearly nothing."""
+    import torch
+    from raytracing_amd import engine, scenes
+    if scene == "atrium":
+        desc = scenes.atrium(16384, res=(96, 54), subdiv=2, tex_size=64, monte_carlo_max=32)
+    else:
+        desc = scenes.instanced(40, 200, res=(96, 54), subdiv=2, monte_carlo_max=32)      # open scene: misses, silhouettes with many rejected attempts
+    PS = engine.package(desc, tables=tables)
+    cam = desc.camera
+    w, h = int(cam["res_x"]), int(cam["res_y"])
+    out = []
+    for env in ({"SRX_SHADE_ROUNDS": "1"}, {"SRX_SHADE_ROUNDS": "2"}, {"SRX_SHADE_ROUNDS": "3", "SRX_SHADE_SPILL_BELOW": "40"},
+                {"SRX_SHADE_ROUNDS": "2", "SRX_SHADE_SPILL_BELOW": "63", "SRX_SHADE_PARK_PCT": "100"},
+                {"SRX_SHADE_ROUNDS": "2", "SRX_SHADE_SPILL_BELOW": "1", "SRX_SHADE_PARK_PCT": "400"}):
+        for k in ("SRX_SHADE_ROUNDS", "SRX_SHADE_SPILL_BELOW", "SRX_SHADE_PARK_PCT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        RE = engine.RayEngine(0)
+        RE.load_scene(PS)
+        acc = torch.zeros((h * w, 4), dtype=torch.float32, device="cuda")
+        cs = [RE.trace_pass(cam, (0, 0, w, h), p, 23, acc, None) for p in range(2)]
+        torch.cuda.synchronize()
+        out.append((acc.cpu().numpy(), cs))
+        RE.close()
+    a0, c0 = out[0]
+    assert int(c0[0]["diffuses_cast"]) > 0 and int(c0[0]["pdf_lookups"]) > int(c0[0]["diffuses_cast"])
+    for a, cs in out[1:]:
+        for ca, cb in zip(cs, c0):
+            for k in ("rays_processed", "diffuses_cast", "shadows_cast", "nodes", "packets", "shadow_nodes", "shadow_packets", "hits",
+                      "texels", "pdf_lookups"):
+                assert int(ca[k]) == int(cb[k]), k
+            assert int(ca["shade_launches"]) > int(cb["shade_launches"])                  # the later rounds were launched
+        assert np.array_equal(a[:, 3], a0[:, 3])
+        assert np.allclose(a[:, :3], a0[:, :3], rtol=1e-4, atol=1e-6, equal_nan=True)
+
+
 def test_converged_image_matches_reference_rng_estimator(tables):
     """Property test at image level: the GPU (keyed per-ray streams, throughput carried down the path, float atomics)
     and the oracle in REFERENCE mode (one sequential xoshiro stream, recursion multiplying on the way back,

@@ -9,6 +9,7 @@ from collections import defaultdict
 def fold(name):
     """k_trace<MODE, K, SPILL> -> k_trace<MODE>, and the one-sun shadow form (MODE 3) under the general form's name (MODE 2)."""
     k = re.sub(r"<(\d), \d(?:, \w+)?>", r"<\1>", name.replace("void ", ""))
+    k = re.sub(r"^k_shade<\d>$", "k_shade", k)          # waves per block
     return "k_trace<2>" if k == "k_trace<3>" else k
 
 tot = defaultdict(float); disp = defaultdict(int)
