@@ -79,6 +79,9 @@ struct srx_renderer {
     GCont* cont[2] = {nullptr, nullptr};
     uint64_t cont_cap[2] = {0, 0};
     uint32_t* d_cont_count = nullptr; // two counters, SRX_COUNT_PAD dwords apart (a third: the hit list's)
+    uint32_t* h_cont_count = nullptr; // pinned [2]: what the last batch parked, checked against the arrays' sizes
+    int last_rounds = 1;              // of the last launch_batch
+    uint64_t last_need[2] = {0, 0};
     // Hit list: in an open scene many rays of the later generations leave the scene, and their lanes sit idle all through
     // the shade kernel. A generation whose batches hit less than `list_below` of the time (what the last batch of that
     // generation did: shadow rays / rays, known to the host anyway) is shaded over the list of its hits instead.
@@ -143,6 +146,7 @@ extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_
     chk(hipMalloc((void**)&r->d_counters, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long)));
     chk(hipHostMalloc((void**)&r->h_counts, 2 * sizeof(DeviceCounts)));
     chk(hipEventCreateWithFlags(&r->round1_done, hipEventDisableTiming));
+    chk(hipHostMalloc((void**)&r->h_cont_count, 2 * sizeof(uint32_t)));
     if (e != hipSuccess) {
         srx_set_error(std::string("srx_renderer_create: ") + hipGetErrorString(e));
         srx_renderer_destroy(r);
@@ -172,6 +176,7 @@ extern "C" void srx_renderer_destroy(srx_renderer* r) {
     (void)hipFree(r->cont[0]); (void)hipFree(r->cont[1]); (void)hipFree(r->d_cont_count); (void)hipFree(r->hit_list);
     if (r->h_counts) (void)hipHostFree(r->h_counts);
     if (r->round1_done) (void)hipEventDestroy(r->round1_done);
+    if (r->h_cont_count) (void)hipHostFree(r->h_cont_count);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -339,6 +344,7 @@ int launch_batch(srx_renderer* r, int gen, const GRay* in, uint32_t n, const uin
         }
     }
     if (t_end(r, ts, r->stream)) return 1;
+    r->last_rounds = rounds; r->last_need[0] = need[0]; r->last_need[1] = need[1];
     if (r->shadow_early) {
         SRX_HIP(hipEventSynchronize(r->round1_done));
         const uint64_t n_shadow = r->h_counts[1].shadow_count;
@@ -484,7 +490,12 @@ int process_segment(srx_renderer* r, int gen, uint64_t begin, uint64_t end) {
         SRX_HIP(hipMemsetAsync(dc, 0, sizeof(DeviceCounts), r->stream));
         if (launch_batch(r, gen, r->rays + begin, (uint32_t)n, nullptr, r->rays + r->top, dc, q, false, 0, nullptr)) return 1;
         SRX_HIP(hipMemcpyAsync(r->h_counts, dc, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
+        for (int k = 0; k + 1 < r->last_rounds; k++)
+            SRX_HIP(hipMemcpyAsync(r->h_cont_count + k, r->d_cont_count + (size_t)k * SRX_COUNT_PAD, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         SRX_HIP(hipStreamSynchronize(r->stream));
+        // a wave parks spill_below loops at most, which is what the arrays were sized by: more would have been dropped
+        for (int k = 0; k + 1 < r->last_rounds; k++)
+            if (r->h_cont_count[k] > r->last_need[k]) SRX_FAIL("srx: internal error, more parked bounce loops than their array holds");
         const uint64_t n_children = r->h_counts->out_count, n_shadow = r->h_counts->shadow_count;
         if (n_children > n * fan || r->top + n_children > r->capacity) SRX_FAIL("srx: internal error, child count exceeds the reserved slots");
         if (n_shadow > n * g.n_suns) SRX_FAIL("srx: internal error, shadow count exceeds the queue");
