@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_shade(GScene sc, ShadeArgs a) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool live = idx < (a.n_ptr ? min(*a.n_ptr, a.n) : a.n);
-    __shared__ GRay s_stage[WAVES][SRX_STAGE];          // per-wave staging of surviving children (36 KB per block: 4 blocks = 16 waves per CU, what 116 VGPRs allow)
+    __shared__ GRay s_stage[WAVES][SRX_STAGE];          // per-wave staging of surviving children (36 KB per block: 4 blocks = 16 waves per CU, what 118 VGPRs allow)
     __shared__ uint32_t s_wave_count[WAVES], s_wave_parked[WAVES];
     __shared__ uint32_t s_base[3];
     GRay* const stage = s_stage[threadIdx.x >> 6];
