@@ -50,10 +50,6 @@ struct srx_renderer {
     DeviceCounts* d_ring = nullptr;
     DeviceCounts* h_ring = nullptr;
     hipEvent_t ring_ev[SRX_RING];
-    // the counts of a link travel back on a stream of their own, behind an event recorded after the link's shade kernel: on
-    // the main stream the copy (a blit kernel: 6 us of dispatch + 3.5 us) sat between that kernel and the next link's traversal
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t link_ev[SRX_RING];
     // kernel timing (set_timing): event pairs from a pool, resolved when the call ends
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -136,10 +132,8 @@ extern "C" int srx_renderer_create(srx_scene* scene, uint64_t ray_capacity, srx_
         chk(hipMalloc((void**)&r->shadow_q[i], r->shadow_capacity * sizeof(GShadow)));
         chk(hipEventCreateWithFlags(&r->shadow_done[i], hipEventDisableTiming));
     }
-    for (int i = 0; i < SRX_RING; i++) { r->ring_ev[i] = nullptr; r->link_ev[i] = nullptr; }
+    for (int i = 0; i < SRX_RING; i++) r->ring_ev[i] = nullptr;
     for (int i = 0; i < SRX_RING; i++) chk(hipEventCreateWithFlags(&r->ring_ev[i], hipEventDisableTiming));
-    for (int i = 0; i < SRX_RING; i++) chk(hipEventCreateWithFlags(&r->link_ev[i], hipEventDisableTiming));
-    chk(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
     chk(hipMalloc((void**)&r->d_ring, SRX_RING * sizeof(DeviceCounts)));
     chk(hipHostMalloc((void**)&r->h_ring, SRX_RING * sizeof(DeviceCounts)));
     chk(hipMalloc((void**)&r->d_counts, 3 * sizeof(DeviceCounts)));
@@ -165,9 +159,7 @@ extern "C" void srx_renderer_destroy(srx_renderer* r) {
         (void)hipFree(r->shadow_q[i]);
         if (r->shadow_done[i]) (void)hipEventDestroy(r->shadow_done[i]);
     }
-    if (r->copy_stream) { (void)hipStreamSynchronize(r->copy_stream); (void)hipStreamDestroy(r->copy_stream); }
     for (int i = 0; i < SRX_RING; i++) if (r->ring_ev[i]) (void)hipEventDestroy(r->ring_ev[i]);
-    for (int i = 0; i < SRX_RING; i++) if (r->link_ev[i]) (void)hipEventDestroy(r->link_ev[i]);
     for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(r->d_ring);
     if (r->h_ring) (void)hipHostFree(r->h_ring);
@@ -414,12 +406,10 @@ int process_chain(srx_renderer* r, int gen, uint64_t begin, uint64_t n) {
         if (retire_shadow(r, q, false)) return 1;            // the shadow kernel that read queue q: the main stream waits on the device
         const uint32_t hint = (uint32_t)std::max(1.0, std::min((double)bound, known * std::pow(ratio, k - known_at)));
         if (launch_batch(r, gen + k, in, bound, n_ptr, region[k & 1], r->d_ring + k, q, true, hint, r->ring_ev[k])) return 1;
-        SRX_HIP(hipEventRecord(r->link_ev[k], r->stream));
-        SRX_HIP(hipStreamWaitEvent(r->copy_stream, r->link_ev[k], 0));
-        SRX_HIP(hipMemcpyAsync(r->h_ring + k, r->d_ring + k, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->copy_stream));
+        SRX_HIP(hipMemcpyAsync(r->h_ring + k, r->d_ring + k, sizeof(DeviceCounts), hipMemcpyDeviceToHost, r->stream));
         // (launch_batch recorded the same event after the shade kernel for the shadow stream to wait on; that wait was
         // enqueued then and keeps referring to that record. This record, after the copy, is the one the host waits for.)
-        SRX_HIP(hipEventRecord(r->ring_ev[k], r->copy_stream));
+        SRX_HIP(hipEventRecord(r->ring_ev[k], r->stream));
         used = k + 1;
         if (gen + k >= g.max_generations) break;              // Core.h:473: this generation queued nothing
         // The host stays at most two links ahead of the device: before link k + 1 is enqueued it has the count of link
@@ -437,7 +427,6 @@ int process_chain(srx_renderer* r, int gen, uint64_t begin, uint64_t n) {
         n_ptr = &r->d_ring[k].out_count;
     }
     SRX_HIP(hipStreamSynchronize(r->stream));
-    SRX_HIP(hipStreamSynchronize(r->copy_stream));
     uint64_t rays = n;
     if (chain_log) {
         std::fprintf(stderr, "srx chain gen %d: %llu", gen, (unsigned long long)n);
@@ -529,7 +518,6 @@ int begin_call(srx_renderer* r) {
     // everything a failed call may have left running is over now (both shadow queues retired above, and every error path
     // of this file comes after a synchronisation of the main stream or leaves nothing enqueued on it that uses sample3)
     SRX_HIP(hipStreamSynchronize(r->stream));
-    SRX_HIP(hipStreamSynchronize(r->copy_stream));
     if (r->sample_dirty && r->sample3) SRX_HIP(hipMemsetAsync(r->sample3, 0, r->sample_pixels * 3 * sizeof(float), r->stream));
     r->sample_dirty = true;           // until end_call
     SRX_HIP(hipMemsetAsync(r->d_counters, 0, (size_t)CTR_SLOTS * CTR_COUNT * sizeof(unsigned long long), r->stream));
