@@ -196,6 +196,12 @@ struct KeyedGen {
     uint64_t s;
     float pool[8];
     __device__ __forceinline__ static uint64_t mix(uint64_t z) {
+#ifdef SRX_EXP_CHEAPRNG   // timing experiment only (a different stream): what the 64-bit multiplies cost
+        uint32_t a = (uint32_t)z, b = (uint32_t)(z >> 32);
+        a = (a ^ (a >> 16)) * 0x7feb352du; b = (b ^ (b >> 15)) * 0x846ca68bu; a ^= b; b += a;
+        a = (a ^ (a >> 15)) * 0x846ca68bu; b = (b ^ (b >> 16)) * 0x7feb352du;
+        return ((uint64_t)(b ^ (b >> 16)) << 32) | (a ^ (a >> 16));
+#endif
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         return z ^ (z >> 31);
