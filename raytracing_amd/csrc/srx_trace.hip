@@ -334,7 +334,11 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) __attribute__((amdgpu_waves_per_
     };
     load_ray_j(oct);
 
+    // closest hit: the nearest hit so far. The shadow forms keep no distance: a ray ends at its first occluder within 9999
+    // (sp = -2 tells finish() it was occluded), a hit beyond 9999 changes nothing (Primitives.h:44-50), and without a distance
+    // there is no cull at the pop: it could only skip boxes beyond a hit that is itself beyond 9999, in scenes larger than that.
     float best_t = SRX_MISS_DISTANCE;
+    int sp = live ? 0 : -1;              // top of the octet's stack; -1: empty, -2 (shadow forms): the ray ended at an occluder
     uint32_t n_nodes = 0, n_packets = 0;
 
     // what the reference returns for one ray (CastResults, Core.h:231-243; SunLight::intersects, Primitives.h:44-50)
@@ -360,17 +364,16 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) __attribute__((amdgpu_waves_per_
                     a.advanced_org3[3 * (size_t)r] = p.x; a.advanced_org3[3 * (size_t)r + 1] = p.y; a.advanced_org3[3 * (size_t)r + 2] = p.z;
                 }
             } else if (MODE == 1) {
-                a.lit[r] = best_t > 9999.0f ? 1 : 0;
+                a.lit[r] = sp != -2 ? 1 : 0;
             }
         }
-        if (SHQ && sub < 3 && best_t > 9999.0f) {
+        if (SHQ && sub < 3 && sp != -2) {
             const GShadow& s = a.shadow_q[r];
             const float c = sub == 0 ? s.cr : (sub == 1 ? s.cg : s.cb);
             if (c != 0.0f) atomicAdd(&a.sample3[3 * (size_t)(s.pixel_sun & 0x00FFFFFFu) + sub], c);
         }
     };
 
-    int sp = live ? 0 : -1;
     if (sub == 0) s_stack[oct] = 0ull;   // root: node 0, distance 0, no packets (Core.h:59-61)
     if (SPILL && sub == 0) s_spilled[oct] = 0u;
     int spill_slot = -1;                 // wave-uniform: this wave's overflow area, claimed at its first spill
@@ -402,12 +405,10 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) __attribute__((amdgpu_waves_per_
                 if (sp < -1) sp = -1;
             }
         } else if (sp >= 0) {
-            // shadow rays: best_t stays at the miss distance until an occluder ends the ray (or, in a scene larger than
-            // 9999 units, a hit beyond 9999 is found), so the cull almost never fires: ONE pop per trip, and an octet
-            // whose entry is culled sits this trip out (same entries visited, same results, no inner loop)
-            const unsigned long long e = s_stack[sp * SRX_OCTETS_PER_BLOCK + oct];
+            // shadow rays: one pop per trip, no cull (above)
+            link = (uint32_t)s_stack[sp * SRX_OCTETS_PER_BLOCK + oct];
             sp--;
-            if (!(u2f((uint32_t)(e >> 32)) >= best_t)) { link = (uint32_t)e; go = true; }
+            go = true;
         }
         if (go) {
             const bool leaf = (link & SRX_LINK_LEAF) != 0u;
@@ -485,21 +486,22 @@ __global__ __launch_bounds__(SRX_TRACE_THREADS) __attribute__((amdgpu_waves_per_
                 const float tt = invDet * __fmaf_rn(e2z, qz, __fmaf_rn(e2y, qy, e2x * qx));
                 const bool pass = (uu >= 0.0f) && (vv >= 0.0f) && ((uu + vv) <= 1.0f);
                 // closest-hit select (Core.h:231-239): lanes in order, strict '<' => lowest lane wins ties
-                const bool cand = pass && (tt > 0.0f) && (tt < best_t);
-                if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
-                    const uint32_t tb = cand ? f2u(tt) : 0xFFFFFFFFu;
-                    const uint32_t m = octet_min_u32(tb);
-                    if (m != 0xFFFFFFFFu) {
-                        best_t = u2f(m);
-                        if (MODE == 0) {
+                const bool cand = pass && (tt > 0.0f) && (MODE == 0 ? tt < best_t : tt <= 9999.0f);
+                const unsigned long long cb = __builtin_amdgcn_ballot_w64(cand);
+                if (cb != 0ull) {
+                    if (MODE == 0) {
+                        const uint32_t tb = cand ? f2u(tt) : 0xFFFFFFFFu;
+                        const uint32_t m = octet_min_u32(tb);
+                        if (m != 0xFFFFFFFFu) {
+                            best_t = u2f(m);
                             const unsigned long long wb = __builtin_amdgcn_ballot_w64(tb == m);
                             const int w = __ffs((int)((uint32_t)(wb >> oct_shift) & 0xFFu)) - 1;
                             // the winning lane records (u, v, where its material and tri_index are) for its octet
                             if (sub == w) s_best[oct] = make_uint4(f2u(uu), f2u(vv), off + 256u + 64u - 12u * (uint32_t)sub, 0u);
-                        } else if (best_t <= 9999.0f) {
-                            sp = -1;   // any occluder nearer than 9999 => shadowed (Primitives.h:44-50)
-                            if (SPILL && spilled_mask != 0ull) s_spilled[oct] = 0u;
                         }
+                    } else if (((uint32_t)(cb >> oct_shift) & 0xFFu) != 0u) {
+                        sp = -2;   // any occluder within 9999 => shadowed (Primitives.h:44-50); the octet's eight lanes agree
+                        if (SPILL && spilled_mask != 0ull) s_spilled[oct] = 0u;
                     }
                 }
             }
